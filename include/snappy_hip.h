@@ -1,0 +1,135 @@
+/*
+ * snappy_hip.h -- C ABI of the MI355X-native Snappy block / framed codec.
+ *
+ * Drop-in boundary for status-im/nim-snappy's in-memory API: every entry point below is what
+ * a Nim `importc, cdecl` binding for that path would bind (the reference's own FFI precedent
+ * is `masked_crc32c`, snappy/codec.nim:66-69, and tests/cpp_snappy.nim:6-11).  Plain pointers
+ * and sizes only.  INTEGRATION.md shows the Nim shim.
+ *
+ * All codec work (block encode, block decode, CRC32C) runs in hand-written HIP kernels for
+ * gfx950.  There is NO CPU fallback: without a usable GPU every codec call returns
+ * SNAPPY_HIP_DEVICE_ERROR (and snappy_hip_last_error() says why).  Only the scalar format
+ * helpers that the reference also computes on the host (size bounds, varint length readers,
+ * the frame-header pre-scan) run on the CPU.
+ *
+ * Status codes: 0 = ok, otherwise 1 + the ordinal of the reference's error enums
+ * (CodecError / FrameError, snappy/codec.nim:55-64).
+ *
+ * Thread safety: like the reference (all `func`, no globals) every call is re-entrant.  The
+ * host-buffer calls serialise on one process-wide device context; callers that want
+ * concurrency create their own context and use the *_ctx / device entry points.
+ */
+#ifndef SNAPPY_HIP_H
+#define SNAPPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SNAPPY_HIP_OK = 0,
+  SNAPPY_HIP_BUFFER_TOO_SMALL = 1, /* CodecError.bufferTooSmall / FrameError.bufferTooSmall */
+  SNAPPY_HIP_INVALID_INPUT = 2,    /* CodecError.invalidInput   / FrameError.invalidInput   */
+  SNAPPY_HIP_CRC_MISMATCH = 3,     /* FrameError.crcMismatch                                */
+  SNAPPY_HIP_UNKNOWN_CHUNK = 4,    /* FrameError.unknownChunk                               */
+  SNAPPY_HIP_DEVICE_ERROR = 100    /* no GPU / HIP failure: never silently falls back       */
+};
+
+/* ---- host-side scalar helpers (the reference computes these on the host too) ------------- */
+
+/* maxCompressedLen, snappy/codec.nim:92-120: 32 + n + n/6. */
+uint64_t snappy_hip_max_compressed_len(uint32_t n);
+/* maxCompressedLenFramed, snappy/codec.nim:140-164. */
+uint64_t snappy_hip_max_compressed_len_framed(int64_t n);
+/* uncompressedLen, snappy/codec.nim:129-138 (u64 varint). 0 ok / 2 invalid. */
+int snappy_hip_uncompressed_len(const uint8_t* in, size_t n, uint64_t* len);
+/* uncompressedLenFramed, snappy/codec.nim:178-214. 0 ok / 2 invalid. */
+int snappy_hip_uncompressed_len_framed(const uint8_t* in, size_t n, uint64_t* len);
+
+/* ---- host-buffer codec API: same contract as snappy.nim, pointers are HOST memory --------- */
+
+/* compress, snappy.nim:27-64.  cap must be >= snappy_hip_max_compressed_len(n). */
+int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+/* uncompress, snappy.nim:84-110. */
+int snappy_hip_uncompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* written);
+/* compressFramed, snappy.nim:130-155.  cap >= snappy_hip_max_compressed_len_framed(n). */
+int snappy_hip_compress_framed(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                               size_t* written);
+/* uncompressFramed, snappy.nim:169-267.  Returns both counters; when the output fills, the
+ * call returns ok with *read at the header of the first chunk that did not fit, so it can be
+ * resumed with check_header = 0 (tests/test_framed.nim:38-59). */
+int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                 int check_header, int check_integrity, size_t* read,
+                                 size_t* written);
+/* maskedCrc, snappy/codec.nim:71-75 -> masked_crc32c, snappy/crc32c.c:759-763.
+ * *status (may be NULL) receives SNAPPY_HIP_OK or SNAPPY_HIP_DEVICE_ERROR. */
+uint32_t snappy_hip_masked_crc32c(const uint8_t* buf, size_t n, int* status);
+/* encodeBlock, snappy/encoder.nim:184-383 (what snappy/faststreams.nim:44,51 and
+ * snappy/streams.nim:38 call).  1 <= n <= 65536, cap >= max_compressed_len(n). */
+int snappy_hip_encode_block(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                            size_t* written);
+/* encodeFrame, snappy/encoder.nim:385-426 (snappy/faststreams.nim:73,80). */
+int snappy_hip_encode_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                            size_t* written);
+/* decodeAllTags, snappy/decoder.nim:20-155. */
+int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                               size_t* written);
+
+/* ---- device-resident batch API (what the GPU needs; the reference has no counterpart) ------
+ * All `d_` pointers are DEVICE memory of the context's GPU.  `stream` is a hipStream_t (NULL =
+ * the context's own stream).  Calls enqueue work and return; use snappy_hip_ctx_sync() or
+ * your own stream synchronisation before reading results.  Block i of a batch is independent:
+ * batches shard across GPUs by block range with no collective. */
+typedef struct snappy_hip_ctx snappy_hip_ctx;
+
+int snappy_hip_ctx_create(snappy_hip_ctx** ctx, int device);
+void snappy_hip_ctx_destroy(snappy_hip_ctx* ctx);
+int snappy_hip_ctx_sync(snappy_hip_ctx* ctx, void* stream);
+/* Human-readable text of the last SNAPPY_HIP_DEVICE_ERROR on this thread. */
+const char* snappy_hip_last_error(void);
+
+/* What one compressed unit is. */
+enum {
+  SNAPPY_HIP_UNIT_BODY = 0,  /* bare tag stream: encodeBlock / decodeAllTags                  */
+  SNAPPY_HIP_UNIT_RAW = 1,   /* varint(len) + tag stream: one compress()/uncompress() buffer  */
+  SNAPPY_HIP_UNIT_FRAME = 2  /* framed chunk: type, len24, masked crc, body (encodeFrame)     */
+};
+
+/* Encode ceil(total_len / block_len) slices of d_in (slice i = d_in[i*block_len ...], the
+ * last may be short; block_len <= 65536), slice i into d_slots + i*slot_stride, its size
+ * into d_sizes[i].  slot_stride >= max_compressed_len(block_len) + 8. */
+int snappy_hip_encode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t total_len,
+                               uint32_t block_len, int unit, uint8_t* d_slots,
+                               uint32_t slot_stride, uint32_t* d_sizes, void* stream);
+/* Second pass of the length-then-data scheme: exclusive scan of d_sizes into
+ * d_offsets[0..n_blocks] (d_offsets[0] = base) and gather of the slots into one contiguous
+ * stream d_out[base ...].  d_total (device, may be NULL) receives d_offsets[n_blocks]. */
+int snappy_hip_pack_d(snappy_hip_ctx* ctx, const uint8_t* d_slots, uint32_t slot_stride,
+                      const uint32_t* d_sizes, uint64_t n_blocks, uint64_t base, uint8_t* d_out,
+                      uint64_t* d_offsets, void* stream);
+/* Decode n_units independent units: unit i = d_in[d_in_off[i] ..+ d_in_len[i]] into
+ * d_out[d_out_off[i] ..+ d_out_cap[i]]; bytes written into d_out_len[i], status into
+ * d_status[i] (SNAPPY_HIP_* codes).  unit = BODY or RAW.  Units that decode to at most 65536
+ * bytes take the block-parallel kernel; larger RAW units take the serial whole-stream kernel.
+ * d_crc (may be NULL) receives the masked CRC32C of each unit's output. */
+int snappy_hip_decode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_in_off,
+                               const uint32_t* d_in_len, uint64_t n_units, int unit,
+                               uint8_t* d_out, const uint64_t* d_out_off,
+                               const uint32_t* d_out_cap, uint32_t* d_out_len,
+                               uint32_t* d_status, uint32_t* d_crc, void* stream);
+/* Masked CRC32C of n_units byte ranges d_in[d_off[i] ..+ d_len[i]] into d_crc[i]. */
+int snappy_hip_crc32c_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_off,
+                        const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc, void* stream);
+/* Average duration in milliseconds of the last timed kernel launches, measured with HIP
+ * events on the launch stream (bench.py's roofline leg).  which: 0 decode, 1 encode, 2 crc,
+ * 3 pack.  Timing is recorded only between snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */
+int snappy_hip_ctx_timing(snappy_hip_ctx* ctx, int enable);
+double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* ctx, int which, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

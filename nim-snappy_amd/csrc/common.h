@@ -1,0 +1,68 @@
+// common.h -- shared definitions for the gfx950 Snappy kernels (wave64, CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snappy_hip {
+
+// ---- format constants (snappy/codec.nim:9-34, :53; snappy/encoder.nim:11-12) ---------------
+constexpr uint32_t kMaxBlockLen = 65536;         // codec.nim:14
+constexpr uint32_t kInputMargin = 15;            // codec.nim:26
+constexpr uint32_t kMinNonLiteral = 17;          // codec.nim:53
+constexpr uint32_t kMaxTableBits = 14;           // encoder.nim:11
+constexpr uint32_t kMaxTableSize = 1u << kMaxTableBits;
+constexpr uint32_t kMaxCompressedBlockLen = 76490;  // codec.nim:217: 32 + 65536 + 65536/6
+constexpr uint32_t kMaskDelta = 0xa282ead8u;        // crc32c.c:49
+
+// Status words shared with include/snappy_hip.h (1 + ordinal of the reference's enums).
+constexpr uint32_t kOk = 0, kBufferTooSmall = 1, kInvalidInput = 2, kCrcMismatch = 3;
+// Internal: the unit does not fit the 64 KiB LDS window, run the whole-stream kernel.
+constexpr uint32_t kNeedsStreamKernel = 0x80000000u;
+
+enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
+
+// ---- wave64 helpers --------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t readfirst(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+
+// Compiler + hardware ordering point for memory that lanes of ONE wave exchange through LDS
+// (LDS operations of a wave execute in issue order; this keeps the compiler from moving them).
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Exclusive prefix sum over the 64 lanes; *total receives the wave sum.
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// Little-endian unaligned accessors.  gfx950 runs with unaligned global / LDS access enabled;
+// hipcc lowers these to single global_load_dword / ds_read_b32 style instructions.
+template <typename P>
+__device__ __forceinline__ uint32_t ld32u(const P* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+template <typename P>
+__device__ __forceinline__ void st32u(P* p, uint32_t v) {
+  __builtin_memcpy(p, &v, 4);
+}
+
+}  // namespace snappy_hip

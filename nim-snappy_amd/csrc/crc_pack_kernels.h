@@ -1,0 +1,175 @@
+// crc_pack_kernels.h -- masked CRC32C and the length-then-data packing pass for gfx950.
+#pragma once
+
+#include "common.h"
+
+namespace snappy_hip {
+
+// ============================================================================================
+// Masked CRC32C (maskedCrc, snappy/codec.nim:71-75 -> masked_crc32c, snappy/crc32c.c:759-763;
+// table algorithm crc32c.c:204-214 / :676-731).
+//
+// One 256-thread workgroup per unit.  The message is right-aligned in rows of 256 dwords
+// (1 KiB); thread t owns column t.  A CRC register is linear over GF(2), so the CRC of the
+// message is the XOR of the CRCs of the 256 "column messages" (column t's dwords in place,
+// zeros elsewhere).  Walking down a column is one Horner step per row:
+//     s <- Z_1024(s ^ dword)              (absorb 4 bytes, then 1020 zero bytes)
+// done with four 256-entry LDS tables (the same shape as slicing-by-4, but for a 1 KiB
+// stride).  Every row is one fully coalesced 1 KiB load per wave; nothing is staged.
+// After its last row a column is advanced over the 4*(256-t) bytes that follow it with one
+// GF(2) polynomial multiplication by x^(32*(256-t)) mod P, and the 256 columns are XOR-ed.
+// The initial 0xffffffff of the register is the XOR of the first four message bytes with ff.
+// ============================================================================================
+constexpr uint32_t kCrcThreads = 256;
+constexpr uint32_t kCrcPoly = 0x82f63b78u;  // reflected Castagnoli
+
+struct CrcParams {
+  const uint8_t* in;
+  const uint64_t* off;
+  const uint32_t* len;
+  uint32_t* crc;
+  uint64_t n_units;
+  const uint32_t* stride_tab;  // [4][256]: Z_1024(b << 8k)
+  const uint32_t* col_mul;     // [256]: x^(32*(256-t)) mod P
+  // fixed-size mode (off == nullptr): unit i = in[i*block_len ..], last one short
+  uint64_t total_len;
+  uint32_t block_len;
+};
+
+// a(x)*b(x) mod P(x), reflected representation (bit 31 = x^0).
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll 4
+  for (int i = 0; i < 32; i++) {
+    p ^= (a & 0x80000000u) ? b : 0;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1) ? kCrcPoly : 0);
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm) {
+  __shared__ uint32_t s_tab[4][256];
+  __shared__ uint32_t s_part[kCrcThreads / 64];
+  const uint32_t t = threadIdx.x;
+  const uint64_t u = blockIdx.x;
+  if (u >= prm.n_units) return;
+  for (uint32_t i = t; i < 1024; i += kCrcThreads) (&s_tab[0][0])[i] = prm.stride_tab[i];
+  __syncthreads();
+
+  const uint8_t* msg;
+  uint32_t n;
+  if (prm.off) {
+    msg = prm.in + prm.off[u];
+    n = prm.len[u];
+  } else {
+    const uint64_t pos = u * (uint64_t)prm.block_len;
+    msg = prm.in + pos;
+    n = (uint32_t)(prm.total_len - pos < prm.block_len ? prm.total_len - pos : prm.block_len);
+  }
+
+  uint32_t reg;  // CRC register before the final inversion
+  if (n < 4) {   // crc32c.c:204-214 territory: too short for the init trick, do it bitwise
+    reg = 0xffffffffu;
+    for (uint32_t i = 0; i < n; i++) {
+      reg ^= msg[i];
+      for (int k = 0; k < 8; k++) reg = (reg >> 1) ^ ((reg & 1) ? kCrcPoly : 0);
+    }
+  } else {
+    const uint32_t row_bytes = 4 * kCrcThreads;
+    const uint32_t rows = (n + row_bytes - 1) / row_bytes;
+    const int64_t pad = (int64_t)rows * row_bytes - n;  // virtual leading zero bytes
+    uint32_t s = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+      const int64_t pos = (int64_t)r * row_bytes + 4 * t - pad;
+      uint32_t w;
+      if (pos >= 4) {
+        w = ld32u(msg + pos);
+      } else {  // touches the message start: virtual zero padding and the 0xffffffff init
+        w = 0;
+        for (int k = 0; k < 4; k++) {
+          const int64_t j = pos + k;
+          if (j >= 0) w |= (uint32_t)(msg[j] ^ (j < 4 ? 0xff : 0)) << (8 * k);
+        }
+      }
+      const uint32_t x = s ^ w;
+      if (r + 1 < rows) {
+        s = s_tab[0][x & 0xff] ^ s_tab[1][(x >> 8) & 0xff] ^ s_tab[2][(x >> 16) & 0xff] ^
+            s_tab[3][x >> 24];
+      } else {
+        s = gf2_mulmod(prm.col_mul[t], x);  // the 4*(256-t) bytes from here to the end
+      }
+    }
+    for (int d = 32; d >= 1; d >>= 1) s ^= __shfl_xor(s, d, 64);
+    if ((t & 63) == 0) s_part[t >> 6] = s;
+    __syncthreads();
+    reg = s_part[0] ^ s_part[1] ^ s_part[2] ^ s_part[3];
+  }
+  if (t == 0) {
+    const uint32_t crc = ~reg;                                // crc32c.c:761
+    prm.crc[u] = ((crc >> 15) | (crc << 17)) + kMaskDelta;    // crc32c.c:762
+  }
+}
+
+// ============================================================================================
+// Packing: the serial `written += ...` of snappy.nim:59-62 / :149-153 as scan + gather.
+// ============================================================================================
+constexpr uint32_t kScanThreads = 1024;
+
+// offsets[0] = base, offsets[i+1] = offsets[i] + sizes[i].  One workgroup, chunked.
+__global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t* sizes,
+                                                                  uint64_t n, uint64_t base,
+                                                                  uint64_t* offsets) {
+  __shared__ uint64_t s_wave[kScanThreads / 64];
+  __shared__ uint64_t s_carry;
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) {
+    s_carry = base;
+    offsets[0] = base;
+  }
+  __syncthreads();
+  for (uint64_t c = 0; c < n; c += kScanThreads) {
+    const uint64_t i = c + t;
+    const uint64_t v = i < n ? sizes[i] : 0;
+    uint64_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint64_t before = s_carry;
+    for (uint32_t k = 0; k < wv; k++) before += s_wave[k];
+    if (i < n) offsets[i + 1] = before + x;
+    __syncthreads();
+    if (t == kScanThreads - 1) s_carry = before + x;
+    __syncthreads();
+  }
+}
+
+// Copy slot i (src = slots + i*stride, sizes[i] bytes) to out + offsets[i].
+// 256 threads per slot; destination is made 16-byte aligned so the body is dwordx4 stores.
+__global__ __launch_bounds__(256) void gather_slots_kernel(const uint8_t* slots, uint32_t stride,
+                                                           const uint32_t* sizes,
+                                                           const uint64_t* offsets,
+                                                           uint64_t n_blocks, uint8_t* out) {
+  const uint64_t b = blockIdx.x;
+  if (b >= n_blocks) return;
+  const uint8_t* src = slots + b * (uint64_t)stride;
+  uint8_t* dst = out + offsets[b];
+  const uint32_t n = sizes[b];
+  const uint32_t t = threadIdx.x;
+  uint32_t head = (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15);
+  if (head > n) head = n;
+  if (t < head) dst[t] = src[t];
+  const uint32_t body = (n - head) & ~15u;
+  for (uint32_t i = t * 16; i < body; i += 256 * 16) {
+    uint4 v;
+    __builtin_memcpy(&v, src + head + i, 16);
+    *reinterpret_cast<uint4*>(dst + head + i) = v;
+  }
+  const uint32_t tail0 = head + body;
+  if (tail0 + t < n) dst[tail0 + t] = src[tail0 + t];
+}
+
+}  // namespace snappy_hip

@@ -1,0 +1,360 @@
+// encode_kernel.h -- bit-exact Snappy block encoder for gfx950 (wave64).
+//
+// Semantics: encodeBlock, snappy/encoder.nim:184-383 (+ emitLiteral :44, emitCopy :81,
+// findMatchLength :130, hash :36, tableSize :27), and the chunk choice of encodeFrame,
+// snappy/encoder.nim:385-426.  Output is byte-identical to the reference encoder: the greedy
+// parse is a strictly sequential algorithm, so one wave EMULATES it exactly for one block:
+//
+//   * the uint16[16384] hash table lives in LDS (32 KiB), zeroed per block like the reference;
+//   * the reference's probe sequence after a literal start is data-independent (skip starts at
+//     32, step = skip>>5): 64 lanes take the next 64 probe positions of that sequence, hash
+//     them, read the table, write their own position, and detect same-slot collisions inside
+//     the wave by reading the slot back; a lane's candidate is the nearest earlier lane with
+//     the same slot, else the table value -- exactly what the sequential loop would have seen;
+//   * the lowest lane whose candidate matches 4 bytes wins (ballot + ctz); table writes of the
+//     lanes after it are rolled back so the table is what the sequential loop leaves behind;
+//   * the copy-loop probe at `ip` right after a copy (encoder.nim:371-380) rides along as lane 0
+//     of the next round, so one round finds either "copy again" or the next literal + copy;
+//   * match extension compares 256 bytes per step across the wave (ballot + ctz);
+//   * elements are emitted through a 4 KiB LDS staging buffer and flushed with wide stores.
+//
+// The sixteen unrolled probes of encoder.nim:280-309 are the first sixteen steps of the same
+// sequence (skip 32..47 => step 1; the guard ipLimit >= ip+16 equals the per-probe guard
+// nextIp <= ipLimit for step 1), so one loop form covers both.
+#pragma once
+
+#include "common.h"
+
+namespace snappy_hip {
+
+constexpr uint32_t kSeqLen = 320;  // probe-sequence entries (offset passes 65536 at ~250)
+constexpr uint32_t kObSize = 4096; // staging bytes
+constexpr uint32_t kObCap = kObSize + 3 * 64 + 16;
+
+struct EncodeParams {
+  const uint8_t* in;
+  uint64_t total_len;
+  uint32_t block_len;
+  int unit;
+  uint8_t* slots;
+  uint32_t slot_stride;
+  uint32_t* sizes;
+  uint64_t n_blocks;
+  const uint32_t* crc;      // kUnitFrame: masked CRC32C per block (crc kernel ran first)
+  const uint32_t* seq_off;  // probe sequence: offset of probe j from the scan start
+  const uint32_t* seq_step; // ... and its step (skip >> 5)
+};
+
+__device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
+  return ((u * 0x1e35a7bdu) >> (32 - kMaxTableBits)) & mask;  // encoder.nim:36-37
+}
+
+__global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
+  __shared__ uint32_t s_seq_off[kSeqLen];
+  __shared__ uint32_t s_seq_step[kSeqLen];
+
+  const uint32_t lane = lane_id();
+  const uint64_t blk = blockIdx.x;
+  if (blk >= prm.n_blocks) return;
+
+  const uint64_t in_pos = blk * (uint64_t)prm.block_len;
+  const uint8_t* in = prm.in + in_pos;
+  const uint32_t n = (uint32_t)(prm.total_len - in_pos < prm.block_len ? prm.total_len - in_pos
+                                                                       : prm.block_len);
+  uint8_t* slot = prm.slots + blk * (uint64_t)prm.slot_stride;
+
+  // ---- unit header -------------------------------------------------------------------------
+  uint32_t body_at = 0;  // where the block body starts inside the slot
+  uint32_t hl = 0;       // varint bytes
+  if (prm.unit != kUnitBody) {
+    const uint32_t base = prm.unit == kUnitFrame ? 8 : 0;
+    uint32_t v = n;
+    uint8_t hb[5];
+    while (v >= 0x80) {
+      hb[hl++] = (uint8_t)(v | 0x80);
+      v >>= 7;
+    }
+    hb[hl++] = (uint8_t)v;
+    if (lane == 0)
+      for (uint32_t i = 0; i < hl; i++) slot[base + i] = hb[i];
+    body_at = base + hl;
+  }
+  uint8_t* gout = slot + body_at;
+
+  uint32_t gpos = 0;   // body bytes already in HBM
+  uint32_t ofill = 0;  // body bytes waiting in s_ob
+
+  auto flush = [&]() {
+    wave_fence();
+    for (uint32_t i = lane * 4; i < ofill; i += 256) {
+      if (i + 4 <= ofill) {
+        st32u(gout + gpos + i, *reinterpret_cast<const uint32_t*>(s_ob + i));
+      } else {
+        for (uint32_t k = i; k < ofill; k++) gout[gpos + k] = s_ob[k];
+      }
+    }
+    gpos += ofill;
+    ofill = 0;
+    wave_fence();
+  };
+  auto reserve = [&](uint32_t bytes) {
+    if (ofill + bytes > kObSize) flush();
+  };
+
+  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
+  auto emit_literal = [&](uint32_t from, uint32_t len) {
+    const uint32_t m = len - 1;
+    const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
+    reserve(w + (len <= 1024 ? len : 0));
+    if (lane == 0) {
+      if (m < 60) {
+        s_ob[ofill] = (uint8_t)(m << 2);
+      } else if (m < 256) {
+        s_ob[ofill] = 60 << 2;
+        s_ob[ofill + 1] = (uint8_t)m;
+      } else {
+        s_ob[ofill] = 61 << 2;
+        s_ob[ofill + 1] = (uint8_t)m;
+        s_ob[ofill + 2] = (uint8_t)(m >> 8);
+      }
+    }
+    ofill += w;
+    if (len <= 1024) {
+      for (uint32_t i = lane * 4; i < len; i += 256) {
+        if (i + 4 <= len) {
+          st32u(s_ob + ofill + i, ld32u(in + from + i));
+        } else {
+          for (uint32_t k = i; k < len; k++) s_ob[ofill + k] = in[from + k];
+        }
+      }
+      ofill += len;
+    } else {  // long literal: HBM -> HBM
+      flush();
+      for (uint32_t i = lane * 4; i < len; i += 256) {
+        if (i + 4 <= len) {
+          st32u(gout + gpos + i, ld32u(in + from + i));
+        } else {
+          for (uint32_t k = i; k < len; k++) gout[gpos + k] = in[from + k];
+        }
+      }
+      gpos += len;
+    }
+  };
+
+  // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
+  auto emit_copy = [&](uint32_t offset, uint32_t length) {
+    uint32_t k64 = length >= 68 ? (length - 68) / 64 + 1 : 0;  // :97-103
+    uint32_t rem = length - 64 * k64;                          // 4..67
+    while (k64) {                                              // <= 64 elements per pass
+      const uint32_t c = k64 < 64 ? k64 : 64;
+      reserve(3 * c);
+      if (lane < c) {
+        s_ob[ofill + 3 * lane] = (63 << 2) | 2;
+        s_ob[ofill + 3 * lane + 1] = (uint8_t)offset;
+        s_ob[ofill + 3 * lane + 2] = (uint8_t)(offset >> 8);
+      }
+      ofill += 3 * c;
+      k64 -= c;
+    }
+    reserve(8);
+    if (lane == 0) {
+      uint32_t o = ofill;
+      if (rem > 64) {  // :105-112
+        s_ob[o] = (59 << 2) | 2;
+        s_ob[o + 1] = (uint8_t)offset;
+        s_ob[o + 2] = (uint8_t)(offset >> 8);
+        o += 3;
+      }
+      const uint32_t r = rem > 64 ? rem - 60 : rem;
+      if (r >= 12 || offset >= 2048) {  // :114-120
+        s_ob[o] = (uint8_t)(((r - 1) << 2) | 2);
+        s_ob[o + 1] = (uint8_t)offset;
+        s_ob[o + 2] = (uint8_t)(offset >> 8);
+      } else {  // :123-125
+        s_ob[o] = (uint8_t)(((offset >> 8) << 5) | ((r - 4) << 2) | 1);
+        s_ob[o + 1] = (uint8_t)offset;
+      }
+    }
+    const uint32_t r = rem > 64 ? rem - 60 : rem;
+    ofill += (rem > 64 ? 3 : 0) + ((r >= 12 || offset >= 2048) ? 3 : 2);
+  };
+
+  if (n < kMinNonLiteral) {  // encoder.nim:227-229
+    if (n) emit_literal(0, n);
+  } else {
+    // ---- per-block setup (encoder.nim:234-245) ---------------------------------------------
+    uint32_t table_size = 1u << 8;
+    while (table_size < kMaxTableSize && table_size < n) table_size <<= 1;
+    const uint32_t mask = table_size - 1;
+    for (uint32_t i = lane * 8; i < table_size; i += 64 * 8)
+      *reinterpret_cast<uint4*>(&s_table[i]) = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane; i < kSeqLen; i += 64) {
+      s_seq_off[i] = prm.seq_off[i];
+      s_seq_step[i] = prm.seq_step[i];
+    }
+    wave_fence();
+    const uint32_t ip_limit = n - kInputMargin;
+
+    bool has0 = false;        // lane 0 carries the copy-loop probe at s0-1
+    uint32_t next_emit = 0;   // start of the pending literal
+    uint32_t s0 = 1;          // position of probe 0 of the current literal scan
+    uint32_t idx0 = 0;        // index into the probe sequence of this round's first scan lane
+    uint32_t tail_from = 0;   // where the final literal starts
+
+    for (;;) {
+      // ---- this round's probe per lane ------------------------------------------------------
+      const bool is0 = has0 && lane == 0;
+      const uint32_t si = idx0 + lane - (has0 ? 1u : 0u);
+      uint32_t p = s0 - 1;
+      bool valid = is0;
+      if (!is0 && si < kSeqLen) {
+        p = s0 + s_seq_off[si];
+        valid = p + s_seq_step[si] <= ip_limit;  // encoder.nim:318-321, before the table write
+      }
+      const uint64_t vmask = ballot(valid);
+      if (vmask == 0) {
+        tail_from = next_emit;
+        break;
+      }
+      const uint32_t d = valid ? ld32u(in + p) : 0;
+      const uint32_t h = snappy_hash(d, mask);
+      const uint32_t old = valid ? s_table[h] : 0;
+      wave_fence();
+      if (valid) s_table[h] = (uint16_t)p;
+      wave_fence();
+      const uint32_t chk = valid ? s_table[h] : p;
+      uint64_t losers = ballot(valid && chk != p);
+
+      // candidate as the sequential loop would see it
+      uint32_t cand = old;
+      uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
+      const bool any_conflict = losers != 0;
+      while (losers) {
+        const uint32_t j = ctz64(losers);
+        const uint32_t hj = readlane(h, j);
+        const uint64_t g = ballot(valid && h == hj);
+        const bool in_g = valid && h == hj;
+        const uint64_t below = g & ((1ull << lane) - 1);
+        const uint32_t pred = below ? 63 - (uint32_t)__builtin_clzll(below) : lane;
+        const uint32_t pp = __shfl(p, pred, 64);
+        if (in_g) {
+          grp = g;
+          if (below) cand = pp;
+        }
+        losers &= ~g;
+      }
+
+      const uint32_t cd = valid ? ld32u(in + cand) : ~d;
+      const uint64_t mm = ballot(valid && cd == d);
+      const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vmask);
+
+      // ---- leave the table as the sequential loop would -------------------------------------
+      if (mm) {
+        wave_fence();
+        if (valid && lane > m_eff) s_table[h] = (uint16_t)old;  // never executed there
+      }
+      if (any_conflict) {
+        wave_fence();
+        // of several lanes <= m_eff on one slot the last one wrote last
+        const uint64_t later = lane >= 63 ? 0 : (grp >> (lane + 1));
+        const uint32_t span = m_eff > lane ? m_eff - lane : 0;  // lanes in (lane, m_eff]
+        const uint64_t later_in = span >= 64 ? later : (later & ((1ull << span) - 1));
+        if (valid && lane <= m_eff && later_in == 0) s_table[h] = (uint16_t)p;
+      }
+      wave_fence();
+
+      if (!mm) {
+        if (vmask == ~0ull) {  // all 64 probes missed: next 64 of the sequence
+          idx0 += has0 ? 63 : 64;
+          has0 = false;
+          continue;
+        }
+        tail_from = next_emit;  // encoder.nim:319-321
+        break;
+      }
+
+      // ---- literal + copy (encoder.nim:336-359) ---------------------------------------------
+      const uint32_t pm = readlane(p, m_eff);
+      const uint32_t c = readlane(cand, m_eff);
+      if (pm > next_emit) emit_literal(next_emit, pm - next_emit);
+
+      uint32_t matched = 4;  // findMatchLength, encoder.nim:130-182: exact, bounded by n
+      {
+        uint32_t a = c + 4, b = pm + 4;
+        for (;;) {
+          const uint32_t pb = b + lane * 4;
+          uint32_t eq = 0;
+          if (pb < n) {
+            const uint32_t avail = n - pb < 4 ? n - pb : 4;
+            const uint32_t sh = 4 - avail;  // keep the dword load inside the block
+            uint32_t x = (ld32u(in + a + lane * 4 - sh) ^ ld32u(in + pb - sh)) >> (8 * sh);
+            eq = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4;
+            if (eq > avail) eq = avail;
+          }
+          const uint64_t mis = ballot(eq < 4);
+          if (mis) {
+            const uint32_t f = ctz64(mis);
+            matched += 4 * f + readlane(eq, f);
+            break;
+          }
+          matched += 256;
+          a += 256;
+          b += 256;
+        }
+      }
+      emit_copy(pm - c, matched);
+      const uint32_t ip = pm + matched;
+      if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
+        tail_from = ip;
+        break;
+      }
+      // encoder.nim:371: table[hash(load32(ip-1))] = ip-1, before the probe at ip
+      if (lane == 0) s_table[snappy_hash(ld32u(in + ip - 1), mask)] = (uint16_t)(ip - 1);
+      wave_fence();
+      has0 = true;
+      s0 = ip + 1;
+      idx0 = 0;
+      next_emit = ip;
+    }
+    if (tail_from < n) emit_literal(tail_from, n - tail_from);  // encoder.nim:249-253
+  }
+  flush();
+  uint32_t body_len = gpos;
+
+  // ---- unit trailer -------------------------------------------------------------------------
+  uint32_t unit_len = body_at + body_len;
+  if (prm.unit == kUnitFrame) {  // encodeFrame, encoder.nim:385-426
+    const bool compressed = n >= kMinNonLiteral && body_len <= n - n / 8;  // :401, :408
+    uint32_t frame_len;
+    if (compressed) {
+      frame_len = hl + body_len + 4;
+    } else {
+      frame_len = n + 4;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      for (uint32_t i = lane * 4; i < n; i += 256) {  // stored chunk: raw bytes after the CRC
+        if (i + 4 <= n) {
+          st32u(slot + 8 + i, ld32u(in + i));
+        } else {
+          for (uint32_t k = i; k < n; k++) slot[8 + k] = in[k];
+        }
+      }
+    }
+    if (lane == 0) {
+      const uint32_t crc = prm.crc[blk];
+      slot[0] = compressed ? 0x00 : 0x01;
+      slot[1] = (uint8_t)frame_len;
+      slot[2] = (uint8_t)(frame_len >> 8);
+      slot[3] = (uint8_t)(frame_len >> 16);
+      slot[4] = (uint8_t)crc;
+      slot[5] = (uint8_t)(crc >> 8);
+      slot[6] = (uint8_t)(crc >> 16);
+      slot[7] = (uint8_t)(crc >> 24);
+    }
+    unit_len = frame_len + 4;
+  }
+  if (lane == 0) prm.sizes[blk] = unit_len;
+}
+
+}  // namespace snappy_hip

@@ -1,0 +1,879 @@
+// snappy_hip.hip -- host side of the C ABI declared in include/snappy_hip.h.
+//
+// Mirrors the reference's in-memory API (snappy.nim) over the gfx950 kernels.  What runs on
+// the host here is only what the reference itself treats as scalar bookkeeping: size bounds,
+// varint length readers and the framed-stream header walk (codec.nim:92-214, the chunk loop
+// of snappy.nim:199-265).  Block encode, block decode and CRC32C always run on the GPU; if
+// HIP is unusable every codec entry point returns SNAPPY_HIP_DEVICE_ERROR.
+#include "../../include/snappy_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "crc_pack_kernels.h"
+#include "decode_kernel.h"
+#include "encode_kernel.h"
+
+using namespace snappy_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+      return SNAPPY_HIP_DEVICE_ERROR;                                                        \
+    }                                                                                        \
+  } while (0)
+
+constexpr uint32_t kSlotStride = 76800;  // >= 8 + 3 + 76490, multiple of 256
+const uint8_t kFramingHeader[10] = {0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59};
+
+// ---- LEB128 (stew/leb128; call sites snappy.nim:49,92, codec.nim:134) ----------------------
+int varint_decode(const uint8_t* in, size_t n, int bits, uint64_t* val) {
+  const int max_len = (bits + 6) / 7;
+  uint64_t v = 0;
+  for (int i = 0; i < max_len && (size_t)i < n; i++) {
+    uint8_t b = in[i];
+    if (i == max_len - 1 && (b >> (bits - 7 * i))) return 0;
+    v |= (uint64_t)(b & 0x7f) << (7 * i);
+    if (!(b & 0x80)) {
+      *val = v;
+      return i + 1;
+    }
+  }
+  return 0;
+}
+
+int varint_encode_u32(uint32_t v, uint8_t* out) {
+  int i = 0;
+  while (v >= 0x80) {
+    out[i++] = (uint8_t)(v | 0x80);
+    v >>= 7;
+  }
+  out[i++] = (uint8_t)v;
+  return i;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct snappy_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t* d_crc_tab = nullptr;   // [4][256]
+  uint32_t* d_col_mul = nullptr;   // [256]
+  uint32_t* d_seq_off = nullptr;   // [kSeqLen]
+  uint32_t* d_seq_step = nullptr;  // [kSeqLen]
+  DevBuf ws[12];                   // grow-only workspace of the host-buffer API
+  bool timing = false;
+  struct Timed {
+    hipEvent_t a, b;
+    int which;
+  };
+  std::vector<Timed> timed;
+  double ms_sum[4] = {0, 0, 0, 0};
+  uint64_t ms_cnt[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int ws_get(snappy_hip_ctx* c, int slot, size_t bytes, void** out) {
+  DevBuf& b = c->ws[slot];
+  if (b.cap < bytes) {
+    if (b.p) HIP_TRY(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return SNAPPY_HIP_OK;
+}
+
+struct LaunchTimer {
+  snappy_hip_ctx* c;
+  hipStream_t s;
+  int which;
+  hipEvent_t a = nullptr, b = nullptr;
+  LaunchTimer(snappy_hip_ctx* c_, hipStream_t s_, int w) : c(c_), s(s_), which(w) {
+    if (c->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+      (void)hipEventRecord(a, s);
+  }
+  ~LaunchTimer() {
+    if (a && b) {
+      (void)hipEventRecord(b, s);
+      c->timed.push_back({a, b, which});
+    }
+  }
+};
+
+hipStream_t pick_stream(snappy_hip_ctx* c, void* stream) {
+  return stream ? (hipStream_t)stream : c->stream;
+}
+
+// CRC tables (crc_pack_kernels.h): generated, the reference's tables are not copied.
+void build_crc_tables(uint32_t* stride_tab, uint32_t* col_mul) {
+  uint32_t t0[256];
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? kCrcPoly : 0);
+    t0[i] = c;
+  }
+  for (uint32_t k = 0; k < 4; k++)
+    for (uint32_t b = 0; b < 256; b++) {
+      uint32_t c = b << (8 * k);
+      for (uint32_t z = 0; z < 4 * kCrcThreads; z++) c = t0[c & 0xff] ^ (c >> 8);
+      stride_tab[k * 256 + b] = c;
+    }
+  for (uint32_t t = 0; t < kCrcThreads; t++) {
+    uint32_t p = 0x80000000u;  // x^0
+    for (uint32_t i = 0; i < 32 * (kCrcThreads - t); i++) p = (p >> 1) ^ ((p & 1) ? kCrcPoly : 0);
+    col_mul[t] = p;
+  }
+}
+
+// The reference's probe sequence (encoder.nim:263-331): skip starts at 32, step = skip >> 5.
+void build_probe_sequence(uint32_t* off, uint32_t* step) {
+  uint32_t skip = 32, o = 0;
+  for (uint32_t j = 0; j < kSeqLen; j++) {
+    step[j] = skip >> 5;
+    off[j] = o;
+    o += step[j];
+    skip += step[j];
+    if (o > (1u << 20)) o = 1u << 20;  // far beyond any block; keep it from wrapping
+  }
+}
+
+}  // namespace
+
+// =============================================================================================
+// context
+// =============================================================================================
+extern "C" const char* snappy_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
+  *out = nullptr;
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) {
+    g_last_error = "no such HIP device";
+    return SNAPPY_HIP_DEVICE_ERROR;
+  }
+  HIP_TRY(hipSetDevice(device));
+  snappy_hip_ctx* c = new snappy_hip_ctx();
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  std::vector<uint32_t> tab(1024), mul(kCrcThreads), so(kSeqLen), ss(kSeqLen);
+  build_crc_tables(tab.data(), mul.data());
+  build_probe_sequence(so.data(), ss.data());
+  HIP_TRY(hipMalloc((void**)&c->d_crc_tab, tab.size() * 4));
+  HIP_TRY(hipMalloc((void**)&c->d_col_mul, mul.size() * 4));
+  HIP_TRY(hipMalloc((void**)&c->d_seq_off, so.size() * 4));
+  HIP_TRY(hipMalloc((void**)&c->d_seq_step, ss.size() * 4));
+  HIP_TRY(hipMemcpy(c->d_crc_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_col_mul, mul.data(), mul.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_seq_off, so.data(), so.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_seq_step, ss.data(), ss.size() * 4, hipMemcpyHostToDevice));
+  *out = c;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& t : c->timed) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  for (auto& b : c->ws)
+    if (b.p) (void)hipFree(b.p);
+  (void)hipFree(c->d_crc_tab);
+  (void)hipFree(c->d_col_mul);
+  (void)hipFree(c->d_seq_off);
+  (void)hipFree(c->d_seq_step);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int snappy_hip_ctx_sync(snappy_hip_ctx* c, void* stream) {
+  HIP_TRY(hipStreamSynchronize(pick_stream(c, stream)));
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_ctx_timing(snappy_hip_ctx* c, int enable) {
+  c->timing = enable != 0;
+  if (enable) {
+    for (auto& t : c->timed) {
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
+    }
+    c->timed.clear();
+    for (int i = 0; i < 4; i++) {
+      c->ms_sum[i] = 0;
+      c->ms_cnt[i] = 0;
+    }
+  }
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_t* launches) {
+  for (auto& t : c->timed) {
+    float ms = 0;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      c->ms_sum[t.which] += ms;
+      c->ms_cnt[t.which] += 1;
+    }
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  c->timed.clear();
+  if (which < 0 || which > 3) return 0;
+  if (launches) *launches = c->ms_cnt[which];
+  return c->ms_cnt[which] ? c->ms_sum[which] / (double)c->ms_cnt[which] : 0.0;
+}
+
+// =============================================================================================
+// device batch API
+// =============================================================================================
+extern "C" int snappy_hip_crc32c_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_off,
+                                   const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc,
+                                   void* stream) {
+  if (n_units == 0) return SNAPPY_HIP_OK;
+  CrcParams p{};
+  p.in = d_in;
+  p.off = d_off;
+  p.len = d_len;
+  p.crc = d_crc;
+  p.n_units = n_units;
+  p.stride_tab = c->d_crc_tab;
+  p.col_mul = c->d_col_mul;
+  hipStream_t s = pick_stream(c, stream);
+  {
+    LaunchTimer lt(c, s, 2);
+    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, p);
+  }
+  HIP_TRY(hipGetLastError());
+  return SNAPPY_HIP_OK;
+}
+
+namespace {
+int crc_fixed_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t total_len, uint32_t block_len,
+                uint32_t* d_crc, hipStream_t s) {
+  uint64_t nb = (total_len + block_len - 1) / block_len;
+  if (nb == 0) return SNAPPY_HIP_OK;
+  CrcParams p{};
+  p.in = d_in;
+  p.crc = d_crc;
+  p.n_units = nb;
+  p.stride_tab = c->d_crc_tab;
+  p.col_mul = c->d_col_mul;
+  p.total_len = total_len;
+  p.block_len = block_len;
+  {
+    LaunchTimer lt(c, s, 2);
+    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)nb), dim3(kCrcThreads), 0, s, p);
+  }
+  HIP_TRY(hipGetLastError());
+  return SNAPPY_HIP_OK;
+}
+}  // namespace
+
+extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in,
+                                          uint64_t total_len, uint32_t block_len, int unit,
+                                          uint8_t* d_slots, uint32_t slot_stride,
+                                          uint32_t* d_sizes, void* stream) {
+  if (block_len == 0 || block_len > kMaxBlockLen || unit < 0 || unit > 2 ||
+      (uint64_t)slot_stride < snappy_hip_max_compressed_len(block_len) + 8) {
+    return SNAPPY_HIP_INVALID_INPUT;
+  }
+  uint64_t nb = (total_len + block_len - 1) / block_len;
+  if (nb == 0) return SNAPPY_HIP_OK;
+  if (nb > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+  hipStream_t s = pick_stream(c, stream);
+  uint32_t* d_crc = nullptr;
+  if (unit == kUnitFrame) {
+    void* p;
+    int st = ws_get(c, 10, nb * 4, &p);
+    if (st) return st;
+    d_crc = (uint32_t*)p;
+    st = crc_fixed_d(c, d_in, total_len, block_len, d_crc, s);
+    if (st) return st;
+  }
+  EncodeParams p{};
+  p.in = d_in;
+  p.total_len = total_len;
+  p.block_len = block_len;
+  p.unit = unit;
+  p.slots = d_slots;
+  p.slot_stride = slot_stride;
+  p.sizes = d_sizes;
+  p.n_blocks = nb;
+  p.crc = d_crc;
+  p.seq_off = c->d_seq_off;
+  p.seq_step = c->d_seq_step;
+  {
+    LaunchTimer lt(c, s, 1);
+    hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64), 0, s, p);
+  }
+  HIP_TRY(hipGetLastError());
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_pack_d(snappy_hip_ctx* c, const uint8_t* d_slots, uint32_t slot_stride,
+                                 const uint32_t* d_sizes, uint64_t n_blocks, uint64_t base,
+                                 uint8_t* d_out, uint64_t* d_offsets, void* stream) {
+  hipStream_t s = pick_stream(c, stream);
+  LaunchTimer lt(c, s, 3);
+  hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_sizes, n_blocks, base,
+                     d_offsets);
+  if (n_blocks)
+    hipLaunchKernelGGL(gather_slots_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, s, d_slots,
+                       slot_stride, d_sizes, d_offsets, n_blocks, d_out);
+  HIP_TRY(hipGetLastError());
+  return SNAPPY_HIP_OK;
+}
+
+namespace {
+int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
+             const uint32_t* d_in_len, uint64_t n_units, int unit, const uint8_t* d_kind,
+             uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+             uint32_t* d_out_len, uint32_t* d_status, bool stream_pass, hipStream_t s) {
+  if (n_units == 0) return SNAPPY_HIP_OK;
+  if (n_units > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+  DecodeParams p{};
+  p.in = d_in;
+  p.in_off = d_in_off;
+  p.in_len = d_in_len;
+  p.out = d_out;
+  p.out_off = d_out_off;
+  p.out_cap = d_out_cap;
+  p.out_len = d_out_len;
+  p.status = d_status;
+  p.kind = d_kind;
+  p.n_units = n_units;
+  p.unit = unit;
+  {
+    LaunchTimer lt(c, s, 0);
+    hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+  }
+  if (stream_pass)
+    hipLaunchKernelGGL(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+  HIP_TRY(hipGetLastError());
+  return SNAPPY_HIP_OK;
+}
+}  // namespace
+
+extern "C" int snappy_hip_decode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in,
+                                          const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint64_t n_units, int unit, uint8_t* d_out,
+                                          const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                          uint32_t* d_out_len, uint32_t* d_status, uint32_t* d_crc,
+                                          void* stream) {
+  if (unit != kUnitBody && unit != kUnitRaw) return SNAPPY_HIP_INVALID_INPUT;
+  hipStream_t s = pick_stream(c, stream);
+  int st = decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off,
+                    d_out_cap, d_out_len, d_status, true, s);
+  if (st) return st;
+  if (d_crc) return snappy_hip_crc32c_d(c, d_out, d_out_off, d_out_len, n_units, d_crc, s);
+  return SNAPPY_HIP_OK;
+}
+
+// =============================================================================================
+// host-side scalar helpers
+// =============================================================================================
+extern "C" uint64_t snappy_hip_max_compressed_len(uint32_t n) {  // codec.nim:117-120
+  return 32u + (uint64_t)n + (uint64_t)n / 6u;
+}
+
+extern "C" uint64_t snappy_hip_max_compressed_len_framed(int64_t n) {  // codec.nim:140-164
+  if (n <= 0) return sizeof kFramingHeader;
+  uint64_t frames = ((uint64_t)n + kMaxBlockLen - 1) / kMaxBlockLen;
+  return (frames - 1) * (kMaxBlockLen + 8) + snappy_hip_max_compressed_len(kMaxBlockLen) + 8 +
+         sizeof kFramingHeader;
+}
+
+extern "C" int snappy_hip_uncompressed_len(const uint8_t* in, size_t n, uint64_t* len) {
+  uint64_t v;
+  if (varint_decode(in, n, 64, &v) <= 0) return SNAPPY_HIP_INVALID_INPUT;  // codec.nim:134-138
+  *len = v;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_uncompressed_len_framed(const uint8_t* in, size_t n, uint64_t* len) {
+  size_t rd = 0;  // codec.nim:178-214
+  uint64_t expected = 0;
+  while (rd < n) {
+    size_t remaining = n - rd;
+    if (remaining < 4) return SNAPPY_HIP_INVALID_INPUT;
+    uint32_t hdr = (uint32_t)in[rd] | ((uint32_t)in[rd + 1] << 8) | ((uint32_t)in[rd + 2] << 16) |
+                   ((uint32_t)in[rd + 3] << 24);
+    uint8_t id = (uint8_t)hdr;
+    size_t data_len = hdr >> 8;
+    if (remaining < data_len + 4) return SNAPPY_HIP_INVALID_INPUT;
+    rd += 4;
+    uint64_t u = 0;
+    if (id == 0x00) {
+      if (data_len < 4) return SNAPPY_HIP_INVALID_INPUT;
+      if (varint_decode(in + rd + 4, data_len - 4, 64, &u) <= 0) return SNAPPY_HIP_INVALID_INPUT;
+    } else if (id == 0x01) {
+      if (data_len < 4) return SNAPPY_HIP_INVALID_INPUT;
+      u = data_len - 4;
+    } else if (id < 0x80) {
+      return SNAPPY_HIP_INVALID_INPUT;
+    }
+    if (u > kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;
+    expected += u;
+    rd += data_len;
+  }
+  *len = expected;
+  return SNAPPY_HIP_OK;
+}
+
+// =============================================================================================
+// host-buffer API
+// =============================================================================================
+namespace {
+
+std::mutex g_mu;
+snappy_hip_ctx* g_ctx = nullptr;
+
+int default_ctx(snappy_hip_ctx** out) {
+  if (!g_ctx) {
+    int dev = 0;
+    if (const char* e = getenv("SNAPPY_HIP_DEVICE")) dev = atoi(e);
+    int st = snappy_hip_ctx_create(&g_ctx, dev);
+    if (st) return st;
+  }
+  HIP_TRY(hipSetDevice(g_ctx->device));
+  *out = g_ctx;
+  return SNAPPY_HIP_OK;
+}
+
+// Encode `n` host bytes as units of `block_len` and land the packed stream (from byte `base`)
+// in out[base ..]; *total = end offset.
+int encode_host(const uint8_t* in, size_t n, int unit, uint8_t* out, size_t cap, uint64_t base,
+                uint64_t* total) {
+  snappy_hip_ctx* c;
+  int st = default_ctx(&c);
+  if (st) return st;
+  const uint64_t nb = (n + kMaxBlockLen - 1) / kMaxBlockLen;
+  void *d_in, *d_slots, *d_sizes, *d_offsets, *d_out;
+  if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
+  if ((st = ws_get(c, 1, nb * (size_t)kSlotStride, &d_slots))) return st;
+  if ((st = ws_get(c, 2, nb * 4, &d_sizes))) return st;
+  if ((st = ws_get(c, 3, (nb + 1) * 8, &d_offsets))) return st;
+  if ((st = ws_get(c, 4, cap + 64, &d_out))) return st;
+  hipStream_t s = c->stream;
+  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  if ((st = snappy_hip_encode_blocks_d(c, (const uint8_t*)d_in, n, kMaxBlockLen, unit,
+                                       (uint8_t*)d_slots, kSlotStride, (uint32_t*)d_sizes, s)))
+    return st;
+  if ((st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes,
+                              nb, base, (uint8_t*)d_out, (uint64_t*)d_offsets, s)))
+    return st;
+  uint64_t end = 0;
+  HIP_TRY(hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (end > cap) {
+    g_last_error = "internal: packed stream exceeds the caller's bound";
+    return SNAPPY_HIP_DEVICE_ERROR;
+  }
+  HIP_TRY(hipMemcpyAsync(out + base, (uint8_t*)d_out + base, end - base, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *total = end;
+  return SNAPPY_HIP_OK;
+}
+
+struct HostUnit {
+  uint64_t in_off;
+  uint32_t in_len;
+  uint64_t out_off;
+  uint32_t out_cap;
+  uint8_t kind;
+};
+
+// Run units on the device: input bytes in[0..n) are uploaded once, outputs land in
+// out[0..out_bytes); per-unit status / length / crc come back in the vectors.
+int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units, uint8_t* out,
+                size_t out_bytes, bool want_crc, std::vector<uint32_t>* status,
+                std::vector<uint32_t>* out_len, std::vector<uint32_t>* crc,
+                bool copy_out = true) {
+  snappy_hip_ctx* c;
+  int st = default_ctx(&c);
+  if (st) return st;
+  const size_t nu = units.size();
+  status->assign(nu, 0);
+  out_len->assign(nu, 0);
+  crc->assign(nu, 0);
+  if (nu == 0) return SNAPPY_HIP_OK;
+  std::vector<uint64_t> io(nu), oo(nu);
+  std::vector<uint32_t> il(nu), oc(nu);
+  std::vector<uint8_t> kd(nu);
+  for (size_t i = 0; i < nu; i++) {
+    io[i] = units[i].in_off;
+    il[i] = units[i].in_len;
+    oo[i] = units[i].out_off;
+    oc[i] = units[i].out_cap;
+    kd[i] = units[i].kind;
+  }
+  void *d_in, *d_out, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_kd, *d_crc;
+  if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
+  if ((st = ws_get(c, 4, out_bytes + 64, &d_out))) return st;
+  if ((st = ws_get(c, 3, nu * 8, &d_io))) return st;
+  if ((st = ws_get(c, 2, nu * 4, &d_il))) return st;
+  if ((st = ws_get(c, 5, nu * 8, &d_oo))) return st;
+  if ((st = ws_get(c, 6, nu * 4, &d_oc))) return st;
+  if ((st = ws_get(c, 7, nu * 4, &d_ol))) return st;
+  if ((st = ws_get(c, 8, nu * 4, &d_st))) return st;
+  if ((st = ws_get(c, 9, nu, &d_kd))) return st;
+  if ((st = ws_get(c, 10, nu * 4, &d_crc))) return st;
+  hipStream_t s = c->stream;
+  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_io, io.data(), nu * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_il, il.data(), nu * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_oo, oo.data(), nu * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_oc, oc.data(), nu * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_kd, kd.data(), nu, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_ol, 0, nu * 4, s));
+  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nu, 0,
+                     (const uint8_t*)d_kd, (uint8_t*)d_out, (const uint64_t*)d_oo,
+                     (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+    return st;
+  if (want_crc) {
+    // CRC of what each unit produced (decoded bytes / stored bytes), snappy.nim:231, :245
+    if ((st = snappy_hip_crc32c_d(c, (const uint8_t*)d_out, (const uint64_t*)d_oo,
+                                  (const uint32_t*)d_ol, nu, (uint32_t*)d_crc, s)))
+      return st;
+    HIP_TRY(hipMemcpyAsync(crc->data(), d_crc, nu * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipMemcpyAsync(status->data(), d_st, nu * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_len->data(), d_ol, nu * 4, hipMemcpyDeviceToHost, s));
+  if (out_bytes && copy_out)
+    HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SNAPPY_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                   size_t* written) {
+  *written = 0;
+  if ((uint64_t)n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:41-42
+  if ((uint64_t)cap < snappy_hip_max_compressed_len((uint32_t)n))    // snappy.nim:44-45
+    return SNAPPY_HIP_BUFFER_TOO_SMALL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int hl = varint_encode_u32((uint32_t)n, out);  // snappy.nim:49-50
+  uint64_t total = (uint64_t)hl;
+  if (n) {
+    int st = encode_host(in, n, kUnitBody, out, cap, (uint64_t)hl, &total);
+    if (st) return st;
+  } else {
+    snappy_hip_ctx* c;  // still refuse to run without a device
+    int st = default_ctx(&c);
+    if (st) return st;
+  }
+  *written = (size_t)total;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_encode_block(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                       size_t* written) {
+  *written = 0;
+  if (n == 0 || n > kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // encoder.nim:208-209
+  if ((uint64_t)cap + 16 <= snappy_hip_max_compressed_len((uint32_t)n))  // encoder.nim:217
+    return SNAPPY_HIP_BUFFER_TOO_SMALL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  uint64_t total = 0;
+  int st = encode_host(in, n, kUnitBody, out, cap, 0, &total);
+  if (st) return st;
+  *written = (size_t)total;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_encode_frame(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                       size_t* written) {
+  *written = 0;
+  if (n == 0 || n > kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // encoder.nim:388
+  if ((uint64_t)cap < snappy_hip_max_compressed_len((uint32_t)n))   // encoder.nim:392
+    return SNAPPY_HIP_BUFFER_TOO_SMALL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  uint64_t total = 0;
+  int st = encode_host(in, n, kUnitFrame, out, cap, 0, &total);
+  if (st) return st;
+  *written = (size_t)total;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_compress_framed(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                          size_t* written) {
+  *written = 0;
+  if ((uint64_t)cap < snappy_hip_max_compressed_len_framed((int64_t)n))  // snappy.nim:139-140
+    return SNAPPY_HIP_BUFFER_TOO_SMALL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  memcpy(out, kFramingHeader, sizeof kFramingHeader);  // snappy.nim:142
+  uint64_t total = sizeof kFramingHeader;
+  if (n) {
+    int st = encode_host(in, n, kUnitFrame, out, cap, sizeof kFramingHeader, &total);
+    if (st) return st;
+  } else {
+    snappy_hip_ctx* c;
+    int st = default_ctx(&c);
+    if (st) return st;
+  }
+  *written = (size_t)total;
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" uint32_t snappy_hip_masked_crc32c(const uint8_t* buf, size_t n, int* status) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto fail = [&](int st) -> uint32_t {
+    if (status) *status = st;
+    return 0;
+  };
+  if (n > 0xffffffffull) return fail(SNAPPY_HIP_INVALID_INPUT);  // crc32c.c:761 truncates; we refuse
+  snappy_hip_ctx* c;
+  int st = default_ctx(&c);
+  if (st) return fail(st);
+  void *d_in, *d_off, *d_len, *d_crc;
+  if ((st = ws_get(c, 0, n + 64, &d_in))) return fail(st);
+  if ((st = ws_get(c, 3, 8, &d_off))) return fail(st);
+  if ((st = ws_get(c, 2, 4, &d_len))) return fail(st);
+  if ((st = ws_get(c, 10, 4, &d_crc))) return fail(st);
+  uint64_t off = 0;
+  uint32_t len = (uint32_t)n, crc = 0;
+  hipStream_t s = c->stream;
+  if (hipMemcpyAsync(d_in, buf, n, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_off, &off, 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_len, &len, 4, hipMemcpyHostToDevice, s) != hipSuccess)
+    return fail(SNAPPY_HIP_DEVICE_ERROR);
+  if ((st = snappy_hip_crc32c_d(c, (const uint8_t*)d_in, (const uint64_t*)d_off,
+                                (const uint32_t*)d_len, 1, (uint32_t*)d_crc, s)))
+    return fail(st);
+  if (hipMemcpyAsync(&crc, d_crc, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return fail(SNAPPY_HIP_DEVICE_ERROR);
+  if (status) *status = SNAPPY_HIP_OK;
+  return crc;
+}
+
+extern "C" int snappy_hip_uncompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                     size_t* written) {
+  *written = 0;
+  uint64_t len;
+  int hdr = varint_decode(in, n, 32, &len);  // snappy.nim:92-94
+  if (hdr <= 0) return SNAPPY_HIP_INVALID_INPUT;
+  if ((uint64_t)cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
+  if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;       // unit lengths are 32-bit
+  std::lock_guard<std::mutex> lk(g_mu);
+  // the kernel re-parses the header: one RAW unit, output window = the declared length
+  std::vector<HostUnit> units{{0, (uint32_t)n, 0, (uint32_t)len, (uint8_t)kUnitRaw}};
+  std::vector<uint32_t> st, ol, crc;
+  int rc = decode_host(in, n, units, out, (size_t)len, false, &st, &ol, &crc);
+  if (rc) return rc;
+  if (st[0] != kOk) return (int)st[0];
+  *written = ol[0];
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                          size_t* written) {
+  *written = 0;
+  if (n == 0) return SNAPPY_HIP_OK;                    // decoder.nim:26-27
+  if (cap == 0) return SNAPPY_HIP_BUFFER_TOO_SMALL;    // decoder.nim:29-30
+  if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;
+  const uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
+  std::lock_guard<std::mutex> lk(g_mu);
+  snappy_hip_ctx* c;
+  int rc = default_ctx(&c);
+  if (rc) return rc;
+  // The output length is not known up front.  A stream of n bytes cannot expand to more than
+  // 64 bytes per 3 (copy2), so the device buffer is bounded by that; the unit's limit stays
+  // the caller's capacity.  Only the bytes actually produced are copied back.
+  const uint64_t bound = (uint64_t)n * 32 + 64;
+  const size_t dev_out = (size_t)(bound < cap32 ? bound : cap32);
+  std::vector<HostUnit> units{{0, (uint32_t)n, 0, cap32, (uint8_t)kUnitBody}};
+  std::vector<uint32_t> st, ol, crc;
+  rc = decode_host(in, n, units, out, dev_out, false, &st, &ol, &crc, false);
+  if (rc) return rc;
+  if (st[0] != kOk) return (int)st[0];
+  if (ol[0]) HIP_TRY(hipMemcpy(out, c->ws[4].p, ol[0], hipMemcpyDeviceToHost));
+  *written = ol[0];
+  return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
+                                            int check_header, int check_integrity,
+                                            size_t* read_out, size_t* written_out) {
+  *read_out = 0;
+  *written_out = 0;
+  if (n > 0xffffffffull * 16) return SNAPPY_HIP_INVALID_INPUT;
+  size_t rd = 0, wr = 0;
+  if (check_header) {  // snappy.nim:187-196
+    if (n < sizeof kFramingHeader) return SNAPPY_HIP_INVALID_INPUT;
+    if (memcmp(in, kFramingHeader, sizeof kFramingHeader) != 0) return SNAPPY_HIP_INVALID_INPUT;
+    rd = sizeof kFramingHeader;
+  }
+  // ---- sequential header walk (host, like codec.nim:178-214): builds the unit list ---------
+  struct Chunk {
+    size_t hdr_at;     // offset of the chunk header
+    size_t end_at;     // offset after the chunk
+    uint32_t crc;      // stored masked CRC
+    bool crc_only;     // stored chunk that is only checksummed (it ends the walk)
+    int after;         // outcome once this chunk's CRC verified: -1 = continue
+  };
+  std::vector<HostUnit> units;
+  std::vector<Chunk> chunks;
+  int terminal = -1;          // status that ends the walk (-1: ran to the end of input)
+  bool stop_ok = false;       // walk ended because the output is full: ok((read-4, written))
+  size_t stop_rd = 0, stop_wr = 0;
+  size_t crc_scratch = 0;  // output-space bytes for crc-only stored chunks (not delivered)
+  while (rd < n) {         // snappy.nim:199
+    size_t remaining = n - rd;
+    if (remaining < 4) {
+      terminal = SNAPPY_HIP_INVALID_INPUT;
+      break;
+    }
+    uint32_t hdr = (uint32_t)in[rd] | ((uint32_t)in[rd + 1] << 8) | ((uint32_t)in[rd + 2] << 16) |
+                   ((uint32_t)in[rd + 3] << 24);
+    uint8_t id = (uint8_t)hdr;
+    size_t data_len = hdr >> 8;
+    size_t hdr_at = rd;
+    rd += 4;
+    if (remaining - 4 < data_len) {  // snappy.nim:206-207
+      terminal = SNAPPY_HIP_INVALID_INPUT;
+      break;
+    }
+    if (id == 0x00) {  // snappy.nim:209-235
+      if (data_len < 4) {
+        terminal = SNAPPY_HIP_INVALID_INPUT;
+        break;
+      }
+      uint32_t crc = (uint32_t)in[rd] | ((uint32_t)in[rd + 1] << 8) | ((uint32_t)in[rd + 2] << 16) |
+                     ((uint32_t)in[rd + 3] << 24);
+      size_t room = cap - wr;
+      size_t max_out = room < kMaxBlockLen ? room : kMaxBlockLen;  // snappy.nim:215
+      uint64_t ulen;
+      int h = varint_decode(in + rd + 4, data_len - 4, 32, &ulen);  // uncompress, snappy.nim:92
+      if (h <= 0) {
+        terminal = SNAPPY_HIP_INVALID_INPUT;
+        break;
+      }
+      if ((uint64_t)max_out < ulen) {  // bufferTooSmall inside the chunk, snappy.nim:219-227
+        uint64_t u64;
+        if (varint_decode(in + rd + 4, data_len - 4, 64, &u64) <= 0 || u64 > kMaxBlockLen) {
+          terminal = SNAPPY_HIP_INVALID_INPUT;
+        } else {
+          stop_ok = true;
+          stop_rd = hdr_at;
+          stop_wr = wr;
+        }
+        break;
+      }
+      units.push_back({rd + 4, (uint32_t)(data_len - 4), wr, (uint32_t)ulen, (uint8_t)kUnitRaw});
+      chunks.push_back({hdr_at, rd + data_len, crc, false, -1});
+      wr += (size_t)ulen;
+    } else if (id == 0x01) {  // snappy.nim:237-257
+      if (data_len < 4) {
+        terminal = SNAPPY_HIP_INVALID_INPUT;
+        break;
+      }
+      uint32_t crc = (uint32_t)in[rd] | ((uint32_t)in[rd + 1] << 8) | ((uint32_t)in[rd + 2] << 16) |
+                     ((uint32_t)in[rd + 3] << 24);
+      size_t ul = data_len - 4;
+      // the reference verifies the CRC BEFORE the size checks (snappy.nim:244-254)
+      if (ul > kMaxBlockLen || ul > cap - wr) {
+        const int after = ul > kMaxBlockLen ? SNAPPY_HIP_INVALID_INPUT : -2;  // -2: output full
+        if (check_integrity) {  // checksum it on the device without delivering it
+          units.push_back({rd + 4, (uint32_t)ul, 0, (uint32_t)ul, (uint8_t)kUnitStored});
+          chunks.push_back({hdr_at, rd + data_len, crc, true, after});
+          crc_scratch = ul;
+        } else if (after == -2) {
+          stop_ok = true;
+          stop_rd = hdr_at;
+          stop_wr = wr;
+        } else {
+          terminal = after;
+        }
+        break;
+      }
+      units.push_back({rd + 4, (uint32_t)ul, wr, (uint32_t)ul, (uint8_t)kUnitStored});
+      chunks.push_back({hdr_at, rd + data_len, crc, false, -1});
+      wr += ul;
+    } else if (id < 0x80) {  // snappy.nim:259-260
+      terminal = SNAPPY_HIP_UNKNOWN_CHUNK;
+      break;
+    }
+    // 0x80..0xff skipped without validation, snappy.nim:262-263
+    rd += data_len;
+  }
+  const size_t walk_rd = rd;
+
+  // ---- device pass ---------------------------------------------------------------------------
+  std::lock_guard<std::mutex> lk(g_mu);
+  // crc-only units write into scratch space placed after the deliverable output
+  const size_t deliver = wr;
+  for (size_t i = 0; i < units.size(); i++)
+    if (chunks[i].crc_only) units[i].out_off = deliver;
+  std::vector<uint32_t> st, ol, crc;
+  std::vector<uint8_t> host_out(deliver + crc_scratch + 1);
+  {
+    snappy_hip_ctx* c;
+    int rc = default_ctx(&c);
+    if (rc) return rc;
+  }
+  int rc = decode_host(in, n, units, host_out.data(), deliver + crc_scratch, check_integrity != 0,
+                       &st, &ol, &crc);
+  if (rc) return rc;
+
+  // ---- first failure in stream order wins ------------------------------------------------------
+  size_t ok_wr = 0;
+  for (size_t i = 0; i < units.size(); i++) {
+    const Chunk& ch = chunks[i];
+    int result = -1;
+    if (units[i].kind == kUnitRaw && st[i] != kOk) {
+      result = SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:228
+    } else if (check_integrity && crc[i] != ch.crc) {
+      result = SNAPPY_HIP_CRC_MISMATCH;  // snappy.nim:231-233, :244-246
+    } else if (ch.crc_only) {
+      result = ch.after;
+    }
+    if (result == -1) {
+      ok_wr += ol[i];
+      continue;
+    }
+    memcpy(out, host_out.data(), ok_wr);  // chunks before the failing one were delivered
+    if (result == -2) {                   // output full at this stored chunk, snappy.nim:253-254
+      *read_out = ch.hdr_at;
+      *written_out = ok_wr;
+      return SNAPPY_HIP_OK;
+    }
+    return result;
+  }
+  memcpy(out, host_out.data(), deliver);
+  if (terminal >= 0) return terminal;
+  if (stop_ok) {
+    *read_out = stop_rd;
+    *written_out = stop_wr;
+    return SNAPPY_HIP_OK;
+  }
+  *read_out = walk_rd;
+  *written_out = deliver;
+  return SNAPPY_HIP_OK;
+}

@@ -1,0 +1,83 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the
+header declares, and its host-side scalar helpers agree with the oracle.  No compute calls
+that need a GPU are made here (except to check that they FAIL loudly without one)."""
+import importlib
+import os
+import re
+
+import pytest
+
+import cases
+from conftest import ROOT, golden_file
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__
+    return __graft_entry__.build()
+
+
+def test_header_and_library_agree(hip):
+    with open(os.path.join(ROOT, "include", "snappy_hip.h")) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(snappy_hip_\w+)\s*\(", text)))
+    assert declared == sorted(hip.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(hip.lib, name), name
+
+
+def test_header_cites_reference(hip):
+    with open(os.path.join(ROOT, "include", "snappy_hip.h")) as fh:
+        text = fh.read()
+    for cite in ("snappy.nim:27", "snappy.nim:84", "snappy.nim:130", "snappy.nim:169",
+                 "encoder.nim:184", "encoder.nim:385", "decoder.nim:20", "codec.nim:71",
+                 "codec.nim:92", "codec.nim:129", "codec.nim:140", "codec.nim:178"):
+        assert cite in text, cite
+
+
+def test_scalar_helpers_match_oracle(hip, orc):
+    for n in (0, 1, 5, 6, 16, 17, 65535, 65536, 65537, 1 << 20, 0xFFFFFFFF):
+        assert hip.max_compressed_len(n) == orc.max_compressed_len(n)
+    for n in (-5, 0, 1, 65536, 65537, 131072, 1 << 32, 1 << 40):
+        assert hip.max_compressed_len_framed(n) == orc.max_compressed_len_framed(n)
+    probes = [b"", b"\x00", b"\x05\x00a", b"\x80\x00", b"\x80", b"\x80\x80\x80\x80\x10",
+              b"\xff\xff\xff\xff\x0f", b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\x01",
+              b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\x02", b"\xff" * 11] + cases.BAD_DATA
+    for p in probes:
+        assert hip.uncompressed_len(p) == orc.uncompressed_len(p), p
+    streams = [golden_file(n) for n in ("alice29.txt.sz-32k", "alice29.txt.sz-64k", "house.jpg.sz")]
+    streams += [cases.FRAMING_HEADER, bytes([3, 2, 1, 0]), bytes([0, 0, 0, 0, 42]),
+                cases.FRAMING_HEADER + b"\x02\x00\x00\x00", cases.FRAMING_HEADER + b"\x80\x03\x00\x00xyz",
+                streams[0][:-1], streams[2][:70000], orc.encode_framed(cases.ramp(70000))]
+    for s in streams:
+        assert hip.uncompressed_len_framed(s) == orc.uncompressed_len_framed(s)
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path must not import, link or call anything under oracle/."""
+    pkg_dir = os.path.join(ROOT, "nim-snappy_amd")
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".nim")):
+                with open(os.path.join(base, f)) as fh:
+                    body = fh.read()
+                assert "pyoracle" not in body and "liboracle" not in body and "sor_" not in body, f
+
+
+def test_fails_loudly_without_gpu(hip):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hip.DeviceError):
+        hip.encode(b"hello hello hello hello hello")
+    with pytest.raises(hip.DeviceError):
+        hip.decode(b"\x05\x10hello")
+    with pytest.raises(hip.DeviceError):
+        hip.masked_crc(b"123456789")
+    with pytest.raises(hip.DeviceError):
+        hip.Context(0)

@@ -1,0 +1,227 @@
+"""Device-resident batch API (the path bench.py measures) against the oracle, on the seeded
+synthetic corpus of SURVEY.md 8d, plus the full-size size-independent properties."""
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__
+    return __graft_entry__.build()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _dev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def _encode_pack(hip, torch, ctx, d_in, total_len, unit, base=0):
+    nb = (total_len + 65535) // 65536
+    d_slots = torch.empty(nb * hip.SLOT_STRIDE, dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(nb, dtype=torch.int32, device="cuda")
+    d_offsets = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+    ctx.encode_blocks(d_in, total_len, d_slots, d_sizes, unit=unit)
+    ctx.sync()
+    total = int(d_sizes.to(torch.int64).sum().item()) + base
+    d_out = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+    ctx.pack(d_slots, d_sizes, nb, d_out, d_offsets, base=base)
+    ctx.sync()
+    assert int(d_offsets[-1].item()) == total
+    return d_slots, d_sizes, d_offsets, d_out, total
+
+
+def test_corpus_sample_bit_exact(hip, orc, torch_mod):
+    """512 mixed blocks: per-block GPU encoding == oracle, packed stream == oracle concat,
+    GPU decode of it == source, statuses ok, CRCs == oracle."""
+    import corpus
+    torch = torch_mod
+    nb = 512
+    blocks = corpus.make_blocks(0, nb)
+    flat = blocks.reshape(-1)
+    ctx = hip.Context(0)
+    d_in = _dev(torch, flat)
+    d_slots, d_sizes, d_offsets, d_out, total = _encode_pack(hip, torch, ctx, d_in, flat.size,
+                                                             hip.UNIT_RAW)
+    sizes = d_sizes.cpu().numpy()
+    packed = d_out[:total].cpu().numpy().tobytes()
+    expect = [orc.encode(blocks[i].tobytes()) for i in range(nb)]
+    assert [int(s) for s in sizes] == [len(e) for e in expect]
+    assert packed == b"".join(expect)
+
+    d_in_len = d_sizes
+    d_in_off = d_offsets[:nb].contiguous()
+    d_out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+    d_out_cap = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
+    d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+    d_crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_dec = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks(d_out, d_in_off, d_in_len, nb, d_dec, d_out_off, d_out_cap, d_out_len,
+                      d_status, unit=hip.UNIT_RAW, d_crc=d_crc)
+    ctx.sync()
+    assert (d_status.cpu().numpy() == 0).all()
+    assert (d_out_len.cpu().numpy() == 65536).all()
+    assert (d_dec.cpu().numpy() == flat).all()
+    crcs = d_crc.cpu().numpy().view(np.uint32)
+    assert [int(c) for c in crcs] == [orc.masked_crc(blocks[i].tobytes()) for i in range(nb)]
+    ctx.close()
+
+
+def test_framed_batch_bit_exact(hip, orc, torch_mod):
+    import corpus
+    torch = torch_mod
+    nb = 96
+    blocks = corpus.make_blocks(1000, nb)
+    flat = blocks.reshape(-1)[:nb * 65536 - 12345]  # ragged last frame
+    ctx = hip.Context(0)
+    d_in = _dev(torch, flat)
+    _, _, _, d_out, total = _encode_pack(hip, torch, ctx, d_in, flat.size, hip.UNIT_FRAME, base=10)
+    got = d_out[:total].cpu().numpy().tobytes()
+    want = orc.encode_framed(flat.tobytes())
+    assert got[10:] == want[10:]  # the 10-byte stream identifier is written by the host API
+    ctx.close()
+
+
+def test_ragged_and_body_units(hip, orc, torch_mod):
+    """short last block, BODY units, tiny total"""
+    torch = torch_mod
+    ctx = hip.Context(0)
+    text = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "golden", "data",
+                                           "lcet10.txt"), "rb").read(), dtype=np.uint8)
+    for total in (1, 16, 17, 65536, 65537, 3 * 65536 + 777):
+        src = text[:total]
+        d_in = _dev(torch, src)
+        d_slots, d_sizes, d_offsets, d_out, tot = _encode_pack(hip, torch, ctx, d_in, total,
+                                                               hip.UNIT_BODY)
+        want = b"".join(orc.encode_block(src[i:i + 65536].tobytes())
+                        for i in range(0, total, 65536))
+        assert d_out[:tot].cpu().numpy().tobytes() == want
+    ctx.close()
+
+
+def test_corrupt_units_match_oracle(hip, orc, torch_mod):
+    """per-unit status of damaged streams == oracle's uncompress verdict"""
+    import corpus
+    torch = torch_mod
+    rng = random.Random(99)
+    nb = 256
+    blocks = corpus.make_blocks(5000, nb)
+    units, caps = [], []
+    for i in range(nb):
+        e = bytearray(orc.encode(blocks[i].tobytes()))
+        kind = rng.randrange(5)
+        if kind == 0:
+            pass
+        elif kind == 1:
+            e[rng.randrange(len(e))] ^= 1 << rng.randrange(8)
+        elif kind == 2:
+            e = e[:rng.randrange(1, len(e))]
+        elif kind == 3:
+            e += bytes([rng.randrange(256)])
+        else:
+            for _ in range(4):
+                e[rng.randrange(len(e))] = rng.randrange(256)
+        units.append(bytes(e))
+        caps.append(65536 if rng.random() < 0.9 else rng.randrange(0, 65536))
+    offs = np.zeros(nb, dtype=np.int64)
+    offs[1:] = np.cumsum([len(u) for u in units])[:-1]
+    ctx = hip.Context(0)
+    d_in = _dev(torch, np.frombuffer(b"".join(units) + bytes(64), dtype=np.uint8))
+    d_in_off = _dev(torch, offs)
+    d_in_len = _dev(torch, np.array([len(u) for u in units], dtype=np.int32))
+    d_out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+    d_out_cap = _dev(torch, np.array(caps, dtype=np.int32))
+    d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+    d_dec = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks(d_in, d_in_off, d_in_len, nb, d_dec, d_out_off, d_out_cap, d_out_len,
+                      d_status, unit=hip.UNIT_RAW)
+    ctx.sync()
+    status = d_status.cpu().numpy()
+    lens = d_out_len.cpu().numpy()
+    dec = d_dec.cpu().numpy()
+    seen = set()
+    for i in range(nb):
+        st, out = orc.uncompress(units[i], caps[i])
+        assert int(status[i]) == st, (i, int(status[i]), st)
+        seen.add(st)
+        if st == 0:
+            assert int(lens[i]) == len(out)
+            assert dec[i * 65536:i * 65536 + len(out)].tobytes() == out
+    assert {0, 1, 2} <= seen
+    ctx.close()
+
+
+def test_large_raw_stream_takes_stream_kernel(hip, orc):
+    """uncompress of a multi-block raw buffer (snappy.nim:84-110): no block delimiters, so it
+    runs on the whole-stream kernel; result identical to the oracle."""
+    src = open(os.path.join(os.path.dirname(__file__), "golden", "data", "kppkn.gtb"), "rb").read()
+    enc = orc.encode(src)
+    assert hip.decode(enc) == src
+    # foreign stream with back-references across 64 KiB boundaries (copy4, decoder.nim:103-109)
+    lit = bytes(range(256)) * 300  # 76 800 bytes
+    stream = bytearray()
+    n = len(lit) + 64
+    v = n
+    while v >= 0x80:
+        stream.append((v & 0x7f) | 0x80)
+        v >>= 7
+    stream.append(v)
+    stream += bytes([62 << 2]) + (len(lit) - 1).to_bytes(3, "little")  # 3 length bytes
+    stream += lit
+    stream += bytes([(63 << 2) | 3]) + (70000).to_bytes(4, "little")  # copy4 len 64 off 70000
+    want = orc.decode(bytes(stream))
+    assert len(want) == n
+    assert hip.decode(bytes(stream)) == want
+
+
+def test_full_size_round_trip_properties(hip, torch_mod):
+    """BASELINE size (65 536 x 64 KiB = 4 GiB; SNAPPY_HIP_TEST_BLOCKS overrides): compress ->
+    pack -> decompress on the device restores every byte, all statuses ok, packed offsets
+    monotone and consistent with the sizes, framed CRC-of-output equals CRC-of-input."""
+    import corpus
+    torch = torch_mod
+    nb = int(os.environ.get("SNAPPY_HIP_TEST_BLOCKS", "16384"))
+    ctx = hip.Context(0)
+    d_in = torch.empty(nb * 65536, dtype=torch.uint8, device="cuda")
+    step = 2048
+    for b0 in range(0, nb, step):
+        c = min(step, nb - b0)
+        d_in[b0 * 65536:(b0 + c) * 65536] = torch.from_numpy(
+            corpus.make_blocks(b0, c).reshape(-1)).cuda()
+    d_slots, d_sizes, d_offsets, d_out, total = _encode_pack(hip, torch, ctx, d_in, nb * 65536,
+                                                             hip.UNIT_RAW)
+    offs = d_offsets.cpu().numpy()
+    sizes = d_sizes.cpu().numpy().astype(np.int64)
+    assert offs[0] == 0 and (np.diff(offs) == sizes).all()
+    assert sizes.max() <= 65536 + 32 + 65536 // 6 and sizes.min() >= 4
+    d_out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+    d_out_cap = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
+    d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+    d_crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_crc_in = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_dec = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks(d_out, d_offsets[:nb].contiguous(), d_sizes, nb, d_dec, d_out_off,
+                      d_out_cap, d_out_len, d_status, unit=hip.UNIT_RAW, d_crc=d_crc)
+    ctx.crc32c(d_in, d_out_off, d_out_cap, nb, d_crc_in)
+    ctx.sync()
+    assert int((d_status != 0).sum().item()) == 0
+    assert int((d_out_len != 65536).sum().item()) == 0
+    assert bool(torch.equal(d_dec, d_in))
+    assert bool(torch.equal(d_crc, d_crc_in))
+    ctx.close()

@@ -1,0 +1,170 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden
+fixtures.  Bar: bit-exact -- this is byte / integer work.  Needs a real MI355X."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import behaviour as bh
+import cases
+from conftest import DATA_FILES, FRAMED_FILES, golden_file
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import __graft_entry__
+    return __graft_entry__.build()
+
+
+# ---- the reference's own test-suite, run against the HIP path ----------------------------------
+def test_reference_block_suite(hip, orc, vectors):
+    bh.check_empty(hip)
+    bh.check_handwritten(hip)
+    bh.check_compresses(hip)
+    bh.check_bad_data(hip)
+    bh.check_baddata_files(hip, vectors)
+    bh.check_literal61_quirk(hip)
+    bh.check_caller_buffer_rules(hip, orc)
+    bh.check_golden_rawsnappy(hip, vectors)
+    for w in cases.WITNESSES:
+        assert bh.check_round_trip(hip, w) == orc.encode(w)
+
+
+@pytest.mark.parametrize("name", DATA_FILES)
+def test_data_files_bit_exact(hip, orc, vectors, name):
+    src = golden_file(name)
+    enc = bh.check_round_trip(hip, src)
+    assert enc == orc.encode(src)  # byte-identical to the reference encoder's restatement
+    assert (len(enc), bh.sha(enc)) == (vectors["files"][name]["oracle_nim_len"],
+                                       vectors["files"][name]["oracle_nim_sha256"])
+    # foreign (C++-semantics) stream of the same data decodes identically too
+    assert hip.decode(orc.encode(src, flags=3)) == src
+
+
+def test_synthetic_patterns_bit_exact(hip, orc):
+    """tests/test_snappy.nim:110-134"""
+    for y in cases.repeat_cases():
+        assert bh.check_round_trip(hip, y) == orc.encode(y)
+    i = 1
+    while i < 20000:
+        buf = cases.mod10(i)
+        assert bh.check_round_trip(hip, buf) == orc.encode(buf)
+        i += 23 * 7  # every 7th size of the reference's sweep keeps the run short
+    for n in cases.block_boundary_lengths():
+        if n % 65536 in (65531, 0, 5):  # edges of each boundary window
+            for buf in (bytes(n), cases.mod10(n)):
+                assert bh.check_round_trip(hip, buf) == orc.encode(buf)
+
+
+def test_every_small_length(hip, orc):
+    """lengths around minNonLiteralBlockSize and the table-size steps (encoder.nim:27-34)"""
+    text = golden_file("alice29.txt")
+    for n in list(range(1, 40)) + [255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096,
+                                   4097, 16383, 16384, 16385, 32768]:
+        src = text[1000:1000 + n]
+        assert hip.encode(src) == orc.encode(src), n
+        assert hip.encode_block(src) == orc.encode_block(src), n
+        assert hip.encode_frame(src) == orc.encode_frame(src), n
+
+
+def test_random_strings(hip, orc):
+    """tests/test_snappy.nim:247-253"""
+    for s in bh.random_strings(0x5EED, count=40):
+        assert bh.check_round_trip(hip, s) == orc.encode(s)
+
+
+def test_block_level_entry_points(hip, orc):
+    src = golden_file("html")[:65536]
+    body = hip.encode_block(src)
+    assert body == orc.encode_block(src)
+    st, out = hip.decode_all_tags(body, 65536)
+    assert st == 0 and out == src
+    st, out = hip.decode_all_tags(body, 100000)  # larger window: written < cap is fine
+    assert st == 0 and out == src
+    st, _ = hip.decode_all_tags(body, 65535)
+    assert st == bh.INVALID_INPUT  # decoder.nim:77-79 / :127-128: not bufferTooSmall
+    assert hip.decode_all_tags(b"", 0) == (0, b"")
+    assert hip.decode_all_tags(b"\x00a", 0)[0] == bh.BUFFER_TOO_SMALL
+    assert hip.encode_frame(src) == orc.encode_frame(src)
+
+
+def test_crc_parity(hip, orc, vectors):
+    pat = bytes((i * 131 + 7) & 0xff for i in range(70000))
+    for k in vectors["crc_kats"]:
+        if "pattern" in k:
+            data = pat[:k["len"]]
+        elif "hex" in k:
+            data = bytes.fromhex(k["hex"])
+        else:
+            data = bytes(k["zeros"])
+        assert hip.masked_crc(data) == k["masked"], k
+    rng = random.Random(5)
+    for n in [1021, 1023, 1024, 1025, 1027, 2047, 2048, 2049, 200000, 1 << 20]:
+        data = rng.randbytes(n)
+        assert hip.masked_crc(data) == orc.masked_crc(data), n
+
+
+# ---- framed --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,target", [("alice29.txt.sz-32k", "alice29.txt"),
+                                         ("alice29.txt.sz-64k", "alice29.txt"),
+                                         ("house.jpg.sz", "house.jpg")])
+def test_framed_golden(hip, name, target):
+    bh.check_framed_golden(hip, name, target)
+
+
+@pytest.mark.parametrize("name", FRAMED_FILES)
+def test_framed_round_trip_bit_exact(hip, orc, name):
+    src = golden_file(name)
+    assert bh.check_framed_round_trip(hip, src) == orc.encode_framed(src)
+
+
+def test_framed_edges(hip):
+    bh.check_framed_edges(hip)
+
+
+def test_framed_error_order(hip, orc):
+    """first failing chunk in stream order decides, exactly as the serial loop"""
+    a, b = cases.mod10(70000), golden_file("html")
+    good = orc.encode_framed(a + b)
+    H = cases.FRAMING_HEADER
+    # corrupt the CRC of the 2nd chunk and the body of the 3rd: crcMismatch wins
+    pos = 10
+    chunks = []
+    while pos < len(good):
+        dl = int.from_bytes(good[pos + 1:pos + 4], "little")
+        chunks.append((pos, dl))
+        pos += 4 + dl
+    assert len(chunks) >= 3
+    bad = bytearray(good)
+    bad[chunks[1][0] + 4] ^= 0xff
+    bad[chunks[2][0] + 12] ^= 0xff
+    for data in (bytes(bad), good[:chunks[2][0] + 9], good + b"\x02\x00\x00\x00"):
+        want = orc.uncompress_framed(data, len(a) + len(b))
+        got = hip.uncompress_framed(data, len(a) + len(b))
+        assert got[0] == want[0]
+        if want[0] == 0:
+            assert got == want
+    assert hip.uncompress_framed(bytes(bad), len(a) + len(b))[0] == bh.CRC_MISMATCH
+
+
+# ---- malformed input: same verdict as the oracle on mutated streams --------------------------------
+def test_mutation_fuzz_matches_oracle(hip, orc):
+    rng = random.Random(1234)
+    seeds = [orc.encode(golden_file("html")[:20000]), orc.encode(cases.mod10(3000)),
+             orc.encode(golden_file("alice29.txt")[:30000]), orc.encode(rng.randbytes(500))]
+    for base in seeds:
+        for _ in range(40):
+            m = bytearray(base)
+            for _ in range(rng.randint(1, 3)):
+                m[rng.randrange(len(m))] = rng.randrange(256)
+            if rng.random() < 0.2:
+                m = m[:rng.randrange(1, len(m))]
+            m = bytes(m)
+            n = orc.uncompressed_len(m)
+            if n is None or n > 1 << 20:
+                assert hip.decode(m) == b""
+                continue
+            assert hip.uncompress(m, n) == orc.uncompress(m, n)
