@@ -125,3 +125,76 @@ def make_blocks(first, count, seed=SEED, mix=None, only=None):
 def class_counts(n_blocks, seed=SEED, mix=None):
     cls = block_classes(0, n_blocks, seed, mix)
     return {name: int((cls == i).sum()) for i, name in enumerate(CLASSES)}
+
+
+# ---- torch mirror (device-side generation for bench.py; equality with the numpy generator is
+# ---- a test: tests/test_corpus.py) -------------------------------------------------------------
+def _t_const(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _t_lsr(torch, z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def _t_mix(torch, z):
+    z = (z ^ _t_lsr(torch, z, 30)) * _t_const(int(_M1))
+    z = (z ^ _t_lsr(torch, z, 27)) * _t_const(int(_M2))
+    return z ^ _t_lsr(torch, z, 31)
+
+
+def _t_umod(torch, z, m):
+    """unsigned 64-bit z mod m for int64-held bit patterns (m < 2^31)"""
+    lo = z & 0xFFFFFFFF
+    hi = _t_lsr(torch, z, 32)
+    return ((hi % m) * ((1 << 32) % m) + (lo % m)) % m
+
+
+def make_blocks_torch(torch, first, count, device, seed=SEED, mix=None, only=None, chunk=1024):
+    """Same bytes as make_blocks(), generated with torch ops on `device` (uint8 [count, 65536])."""
+    mix = MIX if mix is None else mix
+    G = _t_const(int(_G))
+    out = torch.empty((count, BLOCK), dtype=torch.uint8, device=device)
+    idx = torch.arange(first, first + count, dtype=torch.int64, device=device)
+    if only is not None:
+        cls = torch.full((count,), CLASSES.index(only), dtype=torch.int64, device=device)
+    else:
+        r = _t_umod(torch, _t_mix(torch, (idx ^ _t_const(seed)) + G), 100)
+        edges = torch.tensor(np.cumsum(mix), dtype=torch.int64, device=device)
+        cls = torch.searchsorted(edges, r, right=True)
+    state = _t_mix(torch, (idx ^ _t_const(seed)) * 3 + G)
+    ar = torch.arange(BLOCK, dtype=torch.int64, device=device)
+    k8 = (torch.arange(1, BLOCK // 8 + 64 + 1, dtype=torch.int64, device=device)) * G
+    for ci, name in enumerate(CLASSES):
+        sel_all = torch.nonzero(cls == ci).flatten()
+        for c0 in range(0, sel_all.numel(), chunk):
+            sel = sel_all[c0:c0 + chunk]
+            m = sel.numel()
+            if name in ("T_TEXT", "T_HTML"):
+                src = torch.from_numpy(_source(name).copy()).to(device)
+                off = _t_umod(torch, _t_mix(torch, state[sel] + G), src.numel() - BLOCK)
+                out[sel] = src[(off[:, None] + ar[None, :])]
+            elif name == "R":
+                words = _t_mix(torch, state[sel][:, None] + k8[None, :BLOCK // 8])
+                out[sel] = words.contiguous().view(torch.uint8).reshape(m, BLOCK)
+            elif name == "RS":
+                words = _t_mix(torch, state[sel][:, None] + k8[None, :])
+                rnd = words[:, :BLOCK // 8].contiguous().view(torch.uint8).reshape(m, BLOCK)
+                ctl = words[:, BLOCK // 8:]                              # [m, 64]
+                length = 1000 + _t_umod(torch, ctl, 9001)                # string k
+                reps = 2 + _t_umod(torch, _t_lsr(torch, ctl, 32), 3)
+                span = length * reps                                     # output bytes of k
+                ends = torch.cumsum(span, dim=1)                         # [m, 64]
+                used = torch.cumsum(length, dim=1) - length              # source start of k
+                k = torch.searchsorted(ends, ar[None, :].expand(m, BLOCK).contiguous(), right=True)
+                k = k.clamp(max=63)
+                start = torch.gather(ends - span, 1, k)
+                within = (ar[None, :] - start) % torch.gather(length, 1, k)
+                out[sel] = torch.gather(rnd, 1, torch.gather(used, 1, k) + within)
+            elif name == "P10":
+                out[sel] = (ar % 10 + ord("a")).to(torch.uint8)
+            elif name == "Z":
+                out[sel] = 0
+            elif name == "RAMP":
+                out[sel] = (ar & 0xff).to(torch.uint8)
+    return out
