@@ -39,6 +39,7 @@ struct DecodeParams {
   const uint8_t* kind;  // optional per-unit Unit, overrides `unit`
   uint64_t n_units;
   int unit;
+  int dbg;  // timing experiments only: 1 skip literals, 2 skip copies, 4 skip flush
 };
 
 constexpr int kUnitStored = 3;  // internal: verbatim bytes (uncompressed framed chunk)
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     const uint64_t op_next = (uint64_t)__shfl((uint32_t)(dst - op), last, 64) + op + readlane(L, last);
 
     // ---- literals: no dependencies ----------------------------------------------------------
-    {
+    if (!(prm.dbg & 1)) {
       const bool lit = mine && !is_copy;
       if (lit && L <= 16) {  // one element per lane, source in the ring
         const uint64_t qs = (uint64_t)srcv + shift;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     out_fence();
 
     // ---- copies: rounds against the high-water mark ----------------------------------------
-    {
+    if (!(prm.dbg & 2)) {
       uint64_t pending = ballot(mine && is_copy);
       const uint64_t src = dst - srcv;  // valid for copy lanes (offset <= dst checked above)
       while (pending) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
   }
 
   // ---- flush the finished block to HBM, 16 bytes per lane -----------------------------------
-  if (!OUT_GLOBAL) {
+  if (!OUT_GLOBAL && !(prm.dbg & 4)) {
     wave_fence();
     const uint32_t total = (uint32_t)op;
     if (((uintptr_t)gout & 15) == 0) {  // block-aligned output (the batch layouts): b128 both sides

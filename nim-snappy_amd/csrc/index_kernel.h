@@ -1,0 +1,350 @@
+// index_kernel.h -- pass 1 of the v2 block decoder: where do elements start?
+//
+// A Snappy tag stream (snappy/decoder.nim:39-109) can only be split by walking it: whether a
+// byte is a tag or literal payload depends on everything before it.  This kernel breaks that
+// serial chain with lane-parallel speculation, at high occupancy (one wave per unit, ~8 KiB of
+// LDS, no output staging), and leaves a small index behind so that the decode kernel
+// (decode2_kernel.h) can start every 32-byte region of the stream independently:
+//
+//   1. Right-to-left pass, one 32-byte region per lane: for EVERY byte k of the region compute
+//      "if an element started here, where does the element chain leave my region, how many
+//      output bytes and how many copy elements does it produce on the way".  Going right to
+//      left, position k only needs its own element and the already finished entry of k+size,
+//      so all 64 lanes run 32 independent steps (table in LDS, 33-dword row stride = no bank
+//      conflicts).
+//   2. Chain across the 64 regions of a 2 KiB chunk as a fixed-point iteration: lane 0 knows
+//      its true entry; every other lane guesses; each round every lane looks up where a chain
+//      entering at its current guess leaves, and hands that to the next lane.  Lane r is exact
+//      after at most r rounds, in practice after a few (chains that start at different bytes
+//      merge quickly); the loop stops when nothing changes, which is exactly "all correct".
+//   3. A wave prefix sum of the per-region output byte counts gives every region its output
+//      position.
+//
+// Index entry per 32-byte region (u32):  [0:6) offset of the first element in the region
+// (32 = none)  [6:11) copy elements that start in the region  [11:28) output position of
+// that first element.
+//
+// All input-side checks of decodeAllTags (truncated elements, the 61-byte rule of
+// decoder.nim:54-57, 4-byte length wrap :67-68, length bounds :77-79 / :127-128 through the
+// total) are decided here; copy offsets (:112) are checked by the decode kernel.
+#pragma once
+
+#include "common.h"
+#include "decode_kernel.h"
+
+namespace snappy_hip {
+
+constexpr uint32_t kRegion = 32;                    // stream bytes per lane
+constexpr uint32_t kChunk = 64 * kRegion;           // stream bytes per wave step
+constexpr uint32_t kRowStride = kRegion + 1;        // LDS row stride in dwords
+constexpr uint32_t kExitEnd = 0, kExitErr = 1;      // exit field: chain ended / invalid element
+constexpr uint32_t kExitFar = 992;                  // exit field >= 992: far exit, k = value-992
+constexpr uint32_t kOutSat = 0x1ffff;               // saturated output count (> 65536 = invalid)
+constexpr uint32_t kIdxNone = 32;
+
+__device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t ncopy, uint32_t outsum) {
+  return exit_rel | (ncopy << 10) | (outsum << 15);
+}
+__device__ __forceinline__ uint32_t t_exit(uint32_t t) { return t & 1023; }
+__device__ __forceinline__ uint32_t t_ncopy(uint32_t t) { return (t >> 10) & 31; }
+__device__ __forceinline__ uint32_t t_out(uint32_t t) { return t >> 15; }
+
+struct IndexParams {
+  const uint8_t* in;
+  const uint64_t* in_off;
+  const uint32_t* in_len;
+  const uint32_t* out_cap;
+  uint32_t* out_len;
+  uint32_t* status;
+  const uint64_t* idx_off;  // first index entry of each unit (nullptr: u * idx_stride)
+  uint64_t idx_stride;
+  uint32_t* idx;
+  uint64_t n_units;
+  int unit;
+};
+
+// Decode "the element that would start here" from its tag and the four bytes after it.
+// rem = stream bytes after the tag.  Returns false if the element is invalid.
+__device__ __forceinline__ bool decode_element(uint32_t tag, uint32_t b14, uint32_t rem,
+                                               bool* is_copy, uint32_t* L, uint32_t* size,
+                                               uint32_t* hdr, uint32_t* off) {
+  const uint32_t hi6 = tag >> 2, t = tag & 3;
+  bool ok = true;
+  *is_copy = t != 0;
+  *hdr = 1;
+  *off = 0;
+  if (t == 0) {  // decoder.nim:42-84
+    uint32_t len = hi6 + 1, h = 1;
+    if (len >= 61) {
+      ok = rem >= 61;  // decoder.nim:54-57
+      const uint32_t lenlen = len - 60;
+      const uint32_t m = lenlen == 4 ? 0xffffffffu : ((1u << (8 * lenlen)) - 1);
+      len = (b14 & m) + 1;
+      ok = ok && len != 0;  // decoder.nim:67-68
+      h = 1 + lenlen;
+    }
+    ok = ok && !(rem - (h - 1) < len);  // decoder.nim:78
+    *L = len;
+    *hdr = h;
+    *size = h + len;
+  } else if (t == 1) {  // decoder.nim:86-94
+    ok = rem >= 1;
+    *L = 4 + (hi6 & 7);
+    *off = ((tag & 0xe0) << 3) | (b14 & 0xff);
+    *size = 2;
+  } else if (t == 2) {  // decoder.nim:95-102
+    ok = rem >= 2;
+    *L = 1 + hi6;
+    *off = b14 & 0xffff;
+    *size = 3;
+  } else {  // decoder.nim:103-109
+    ok = rem >= 4;
+    *L = 1 + hi6;
+    *off = b14;
+    *size = 5;
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
+  __shared__ uint32_t s_tab[64 * kRowStride];
+
+  const uint32_t lane = lane_id();
+  const uint64_t u = blockIdx.x;
+  if (u >= prm.n_units) return;
+  const uint8_t* in0 = prm.in + prm.in_off[u];
+  uint32_t n = prm.in_len[u];
+  const uint32_t cap = prm.out_cap[u];
+  uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride);
+
+  auto finish = [&](uint32_t st, uint32_t written) {
+    if (lane == 0) {
+      prm.status[u] = st;
+      prm.out_len[u] = written;
+    }
+  };
+
+  // ---- header: identical to decode_units_kernel ---------------------------------------------
+  uint32_t limit;
+  bool exact = false;
+  if (prm.unit == kUnitRaw) {
+    uint32_t ulen = 0, hdr = 0;
+    if (lane == 0) hdr = parse_varint32(in0, n, &ulen);
+    hdr = readfirst(hdr);
+    ulen = readfirst(ulen);
+    if (hdr == 0) return finish(kInvalidInput, 0);
+    if (cap < ulen) return finish(kBufferTooSmall, 0);
+    if (ulen == 0) return finish(hdr == n ? kOk : kInvalidInput, 0);
+    in0 += hdr;
+    n -= hdr;
+    limit = ulen;
+    exact = true;
+  } else {
+    if (n == 0) return finish(kOk, 0);
+    if (cap == 0) return finish(kBufferTooSmall, 0);
+    limit = cap;
+  }
+  if (exact && limit > kMaxBlockLen) return finish(kNeedsStreamKernel, 0);
+  const uint32_t win_limit = limit < kMaxBlockLen ? limit : kMaxBlockLen;
+  // what an over-long output means: a bigger unit goes to the whole-stream kernel
+  const uint32_t too_long = limit > win_limit ? kNeedsStreamKernel : kInvalidInput;
+
+  const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
+  const uint8_t* g0 = in0 - shift;                          // 16-byte aligned
+  const uint64_t g_end = ((uint64_t)shift + n + 15) & ~15ull;  // aligned end of the unit
+
+  uint64_t entry_abs = 0;  // stream position of the next real element (uniform)
+  uint64_t op = 0;         // output bytes before it (uniform)
+  bool ended = false;
+  const uint32_t row = lane * kRowStride;
+
+  for (uint64_t c0 = 0; c0 < n && !ended; c0 += kChunk) {
+    const uint64_t rs = c0 + (uint64_t)lane * kRegion;  // my region's first stream position
+    uint32_t entry_off = kIdxNone, out_here = 0, ncopy_here = 0;
+
+    if (entry_abs < c0 + kChunk) {  // otherwise a long literal covers the whole chunk
+      // ---- my 32 region bytes + 8 bytes lookahead, from 16-byte aligned loads ---------------
+      uint32_t w[10];
+      {
+        uint32_t a[16];
+        const uint64_t q = rs + shift;
+        const uint64_t qa = q & ~15ull;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (qa + 16 * i < g_end) v = *reinterpret_cast<const uint4*>(g0 + qa + 16 * i);
+          a[4 * i] = v.x;
+          a[4 * i + 1] = v.y;
+          a[4 * i + 2] = v.z;
+          a[4 * i + 3] = v.w;
+        }
+        const uint32_t sh = (uint32_t)(q & 15);
+        const uint32_t dsh = sh >> 2, bsh = (sh & 3) * 8;
+        // dword-granular part of the shift with selects, byte part with a funnel shift
+        uint32_t b[11];
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+          b[i] = dsh == 0 ? a[i] : dsh == 1 ? a[i + 1] : dsh == 2 ? a[i + 2] : a[i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) w[i] = __funnelshift_r(b[i], b[i + 1], bsh);
+      }
+
+      // ---- right-to-left pass over my 32 positions --------------------------------------------
+#pragma unroll
+      for (int k = kRegion - 1; k >= 0; k--) {
+        const uint64_t p = rs + k;
+        uint32_t t;
+        if (p >= n) {
+          t = t_pack(kExitEnd, 0, 0);
+        } else {
+          const uint32_t lo = w[k >> 2], hi = w[(k >> 2) + 1], hi2 = w[(k >> 2) + 2];
+          const uint32_t sh8 = (k & 3) * 8;
+          const uint32_t d0 = sh8 ? __funnelshift_r(lo, hi, sh8) : lo;   // bytes k..k+3
+          const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
+          const uint32_t tag = d0 & 0xff;
+          const uint32_t b14 = (d0 >> 8) | (d1 << 24);
+          const uint64_t rem64 = (uint64_t)n - p - 1;
+          const uint32_t rem = rem64 > 0xffffffffull ? 0xffffffffu : (uint32_t)rem64;
+          bool is_copy;
+          uint32_t L, size, hdr, off;
+          const bool ok = decode_element(tag, b14, rem, &is_copy, &L, &size, &hdr, &off);
+          const uint32_t Ls = L < kOutSat ? L : kOutSat;
+          if (!ok) {
+            t = t_pack(kExitErr, 0, 0);
+          } else {
+            const uint64_t nx = (uint64_t)k + size;
+            if (nx >= kRegion) {
+              t = t_pack(nx < kExitFar ? (uint32_t)nx : kExitFar + (uint32_t)k, is_copy ? 1 : 0, Ls);
+            } else {
+              const uint32_t tn = s_tab[row + (uint32_t)nx];
+              if (t_exit(tn) == kExitErr) {
+                t = tn;
+              } else {
+                uint32_t o = Ls + t_out(tn);
+                if (o > kOutSat) o = kOutSat;
+                t = t_pack(t_exit(tn), t_ncopy(tn) + (is_copy ? 1 : 0), o);
+              }
+            }
+          }
+        }
+        s_tab[row + k] = t;
+      }
+      wave_fence();
+
+      // ---- chain across the regions: fixed point ------------------------------------------------
+      // in_abs = stream position at which the element chain arrives at my region (>= rs)
+      uint64_t in_abs = lane == 0 ? entry_abs : rs;
+      uint64_t out_abs;
+      uint32_t tv = 0;
+      bool has;
+      for (;;) {
+        has = in_abs < rs + kRegion;
+        out_abs = in_abs;
+        if (has) {
+          tv = s_tab[row + (uint32_t)(in_abs - rs)];
+          const uint32_t ex = t_exit(tv);
+          if (ex == kExitEnd || ex == kExitErr) {
+            out_abs = ~0ull;  // nothing follows
+          } else if (ex >= kExitFar) {
+            // far exit: a long literal at offset ex-992; re-read its header from HBM (rare)
+            const uint64_t fp = rs + (ex - kExitFar);
+            const uint32_t ftag = in0[fp];
+            uint32_t fb = 0;
+            for (uint32_t i = 0; i < 4 && fp + 1 + i < n; i++) fb |= (uint32_t)in0[fp + 1 + i] << (8 * i);
+            bool c;
+            uint32_t L, size, hdr, off;
+            decode_element(ftag, fb, 0xffffffffu, &c, &L, &size, &hdr, &off);
+            out_abs = fp + size;
+          } else {
+            out_abs = rs + ex;
+          }
+        }
+        uint32_t lo = __shfl_up((uint32_t)out_abs, 1, 64);
+        uint32_t hi = __shfl_up((uint32_t)(out_abs >> 32), 1, 64);
+        const uint64_t nin = lane == 0 ? entry_abs : (((uint64_t)hi << 32) | lo);
+        const bool changed = nin != in_abs;
+        in_abs = nin;
+        if (!ballot(changed)) break;
+      }
+
+      // ---- verdicts and this chunk's contribution ---------------------------------------------------
+      const bool bad = has && t_exit(tv) == kExitErr;
+      if (ballot(bad)) return finish(kInvalidInput, 0);
+      if (has && in_abs < n) {  // in_abs == n is the end of the stream, not an element
+        entry_off = (uint32_t)(in_abs - rs);
+        out_here = t_out(tv);
+        ncopy_here = t_ncopy(tv);
+      }
+      ended = ballot(has && t_exit(tv) == kExitEnd) != 0;
+      const uint32_t last_lo = readlane((uint32_t)out_abs, 63);
+      const uint32_t last_hi = readlane((uint32_t)(out_abs >> 32), 63);
+      entry_abs = ((uint64_t)last_hi << 32) | last_lo;
+    }
+
+    // output positions: saturating counts keep the sum below 2^32 (64 * 0x1ffff)
+    uint32_t tot;
+    const uint32_t before = wave_excl_scan(out_here, lane, &tot);
+    if (op + tot > win_limit) return finish(too_long, 0);
+    if (rs < n) {
+      const uint32_t pos = (uint32_t)op + before;
+      idx[rs / kRegion] = entry_off | (ncopy_here << 6) | (pos << 11);
+    }
+    op += tot;
+  }
+
+  // the chain must consume the stream exactly (every element was bounds-checked against n)
+  if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
+  if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
+  finish(kOk, (uint32_t)op);
+}
+
+
+// DEBUG: serial check of the index of one unit against a plain walk (one thread per unit).
+// report[u*4..]: region of the first mismatch (or ~0), expected entry, got entry.
+__global__ void verify_index_kernel(IndexParams prm, uint32_t* report) {
+  const uint64_t u = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (u >= prm.n_units) return;
+  report[u * 4] = 0xffffffffu;
+  if (prm.status[u] != kOk || prm.out_len[u] == 0) return;
+  const uint8_t* in0 = prm.in + prm.in_off[u];
+  uint32_t n = prm.in_len[u];
+  if (prm.unit == kUnitRaw) {
+    uint32_t hdr = 0;
+    while (in0[hdr] & 0x80) hdr++;
+    hdr++;
+    in0 += hdr;
+    n -= hdr;
+  }
+  const uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride);
+  uint32_t pos = 0, dst = 0;
+  const uint32_t nreg = (n + kRegion - 1) / kRegion;
+  for (uint32_t r = 0; r < nreg; r++) {
+    const uint32_t rs = r * kRegion;
+    uint32_t want = kIdxNone | (dst << 11);
+    if (pos < rs + kRegion && pos < n) {
+      uint32_t e_off = pos - rs, d0 = dst, nc = 0;
+      while (pos < rs + kRegion && pos < n) {
+        uint32_t b = 0;
+        for (uint32_t i = 0; i < 4 && pos + 1 + i < n; i++) b |= (uint32_t)in0[pos + 1 + i] << (8 * i);
+        bool c;
+        uint32_t L, size, hdr, off;
+        decode_element(in0[pos], b, 0xffffffffu, &c, &L, &size, &hdr, &off);
+        nc += c ? 1 : 0;
+        dst += L;
+        pos += size;
+      }
+      want = e_off | (nc << 6) | (d0 << 11);
+    }
+    const uint32_t got = idx[r];
+    const bool same = (want & 63) == kIdxNone ? (got & 63) == kIdxNone : got == want;
+    if (!same) {
+      report[u * 4] = r;
+      report[u * 4 + 1] = want;
+      report[u * 4 + 2] = got;
+      return;
+    }
+  }
+}
+
+}  // namespace snappy_hip

@@ -17,8 +17,10 @@
 
 #include "common.h"
 #include "crc_pack_kernels.h"
+#include "decode2_kernel.h"
 #include "decode_kernel.h"
 #include "encode_kernel.h"
+#include "index_kernel.h"
 
 using namespace snappy_hip;
 
@@ -78,7 +80,7 @@ struct snappy_hip_ctx {
   uint32_t* d_col_mul = nullptr;   // [256]
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
-  DevBuf ws[12];                   // grow-only workspace of the host-buffer API
+  DevBuf ws[16];                   // grow-only workspace of the host-buffer API
   bool timing = false;
   struct Timed {
     hipEvent_t a, b;
@@ -368,9 +370,76 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   p.kind = d_kind;
   p.n_units = n_units;
   p.unit = unit;
-  {
+  if (const char* e = getenv("SNAPPY_HIP_DBG")) p.dbg = atoi(e);
+  const bool v1 = d_kind != nullptr || getenv("SNAPPY_HIP_DECODE_V1") != nullptr;
+  if (v1) {
     LaunchTimer lt(c, s, 0);
     hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+  } else {
+    // v2: index pass (where do elements start) + indexed block decode
+    const uint64_t stride = kMaxRegionsPerUnit;
+    void *d_idx, *d_cnt = nullptr, *d_ioff = nullptr;
+    int st;
+    if (n_units * stride * 4 <= (4ull << 30)) {
+      if ((st = ws_get(c, 13, n_units * stride * 4, &d_idx))) return st;
+    } else {
+      // many units: compact index, sized by a scan of the per-unit region counts
+      if ((st = ws_get(c, 11, n_units * 4, &d_cnt))) return st;
+      if ((st = ws_get(c, 12, (n_units + 1) * 8, &d_ioff))) return st;
+      hipLaunchKernelGGL(region_counts_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256),
+                         0, s, d_in_len, n_units, (uint32_t*)d_cnt);
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s,
+                         (const uint32_t*)d_cnt, n_units, (uint64_t)0, (uint64_t*)d_ioff);
+      uint64_t total = 0;
+      HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)d_ioff + n_units, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if ((st = ws_get(c, 13, total * 4 + 64, &d_idx))) return st;
+    }
+    IndexParams ip{};
+    ip.in = d_in;
+    ip.in_off = d_in_off;
+    ip.in_len = d_in_len;
+    ip.out_cap = d_out_cap;
+    ip.out_len = d_out_len;
+    ip.status = d_status;
+    ip.idx_off = (const uint64_t*)d_ioff;
+    ip.idx_stride = stride;
+    ip.idx = (uint32_t*)d_idx;
+    ip.n_units = n_units;
+    ip.unit = unit;
+    Decode2Params dp{};
+    dp.in = d_in;
+    dp.in_off = d_in_off;
+    dp.in_len = d_in_len;
+    dp.out = d_out;
+    dp.out_off = d_out_off;
+    dp.out_len = d_out_len;
+    dp.status = d_status;
+    dp.idx_off = (const uint64_t*)d_ioff;
+    dp.idx_stride = stride;
+    dp.idx = (const uint32_t*)d_idx;
+    dp.n_units = n_units;
+    dp.unit = unit;
+    LaunchTimer lt(c, s, 0);
+    hipLaunchKernelGGL(index_units_kernel, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+    if (getenv("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
+      uint32_t* d_rep;
+      HIP_TRY(hipMalloc((void**)&d_rep, n_units * 16));
+      hipLaunchKernelGGL(verify_index_kernel, dim3((uint32_t)((n_units + 63) / 64)), dim3(64), 0, s, ip, d_rep);
+      std::vector<uint32_t> rep(n_units * 4);
+      HIP_TRY(hipMemcpyAsync(rep.data(), d_rep, n_units * 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      int shown = 0;
+      for (uint64_t i = 0; i < n_units; i++)
+        if (rep[i * 4] != 0xffffffffu && shown++ < 12)
+          fprintf(stderr, "INDEX MISMATCH unit %llu region %u (chunk %u lane %u): want off %u nc %u dst %u, got off %u nc %u dst %u\n",
+                  (unsigned long long)i, rep[i * 4], rep[i * 4] / 64, rep[i * 4] % 64, rep[i * 4 + 1] & 63,
+                  (rep[i * 4 + 1] >> 6) & 31, rep[i * 4 + 1] >> 11, rep[i * 4 + 2] & 63,
+                  (rep[i * 4 + 2] >> 6) & 31, rep[i * 4 + 2] >> 11);
+      fprintf(stderr, "index verify: %d units with a mismatch\n", shown);
+      (void)hipFree(d_rep);
+    }
+    hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
   }
   if (stream_pass)
     hipLaunchKernelGGL(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
