@@ -13,9 +13,11 @@ workload: configs[1] of BASELINE.json -- 1 x MI355X block DECOMPRESS of 65 536 x
 multi-GPU: every rank owns its own 65 536-block range of the corpus (weak scaling, no data-path
           collective -- blocks are independent); value = all ranks' bytes / max time.
 
-roofline : the decode kernel is HBM-bound byte work.  achieved = (sum C + sum U) per launch /
-          average kernel duration, measured with HIP events on the launch stream inside the timed
-          region (snappy_hip_ctx_kernel_ms).  peak = 8000 GB/s (MI355X_MICROARCH.md).
+roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel (pass 2
+          of the v2 decoder; pass 1, index_units_kernel, is reported beside it).  achieved =
+          (sum C + sum U) per launch / average kernel duration, measured with HIP events on the
+          launch stream inside the timed region (snappy_hip_ctx_kernel_ms).
+          peak = 8000 GB/s (MI355X_MICROARCH.md).
 cpu_baseline: the CPU oracle (oracle/snappy_oracle.c, a bit-exact restatement of the reference --
           the Nim reference itself cannot be built here) timed single-threaded on this box on a
           bounded sample of the same blocks.  kind = "port".
@@ -107,6 +109,7 @@ def main():
 
     hip = importlib.import_module("nim-snappy_amd")  # raises if the HIP library is missing
     import corpus
+    import shard
     ctx = hip.Context(local)
     nb = args.blocks
 
@@ -115,8 +118,8 @@ def main():
     for b0 in range(0, nb, 4096):
         c = min(4096, nb - b0)
         d_in[b0 * BLOCK:(b0 + c) * BLOCK] = corpus.make_blocks_torch(
-            torch, rank * nb + b0, c, dev, only=args.only).reshape(-1)
-    chk = corpus.make_blocks(rank * nb, 8, only=args.only).reshape(-1)
+            torch, shard.first_block(rank, nb) + b0, c, dev, only=args.only).reshape(-1)
+    chk = corpus.make_blocks(shard.first_block(rank, nb), 8, only=args.only).reshape(-1)
     assert np.array_equal(d_in[:8 * BLOCK].cpu().numpy(), chk), "device corpus != numpy corpus"
 
     # ---- compress on the device (also gives the compress number) -----------------------------------
@@ -184,12 +187,10 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    dec_ms, dec_launches = ctx.kernel_ms(0)
+    dec_ms, dec_launches = ctx.kernel_ms(0)   # decode_indexed_kernel (dominant)
+    idx_ms, _ = ctx.kernel_ms(4)               # index_units_kernel
     ctx.timing(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist if world > 1 else None, elapsed, dev)
 
     # results must be right, or the number is void
     assert int((d_status != 0).sum().item()) == 0, "decode reported errors"
@@ -235,8 +236,9 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": None,
-                "kernel": "decode_units_kernel<false>",
+                "kernel": "decode_indexed_kernel",
                 "kernel_ms": round(dec_ms, 4),
+                "index_pass_kernel_ms": round(idx_ms, 4),
                 "launches": dec_launches,
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },

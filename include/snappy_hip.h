@@ -106,7 +106,7 @@ int snappy_hip_encode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_
                                uint32_t slot_stride, uint32_t* d_sizes, void* stream);
 /* Second pass of the length-then-data scheme: exclusive scan of d_sizes into
  * d_offsets[0..n_blocks] (d_offsets[0] = base) and gather of the slots into one contiguous
- * stream d_out[base ...].  d_total (device, may be NULL) receives d_offsets[n_blocks]. */
+ * stream d_out[base ...]; the end of the stream is d_offsets[n_blocks]. */
 int snappy_hip_pack_d(snappy_hip_ctx* ctx, const uint8_t* d_slots, uint32_t slot_stride,
                       const uint32_t* d_sizes, uint64_t n_blocks, uint64_t base, uint8_t* d_out,
                       uint64_t* d_offsets, void* stream);
@@ -124,8 +124,10 @@ int snappy_hip_decode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const u
 int snappy_hip_crc32c_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_off,
                         const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc, void* stream);
 /* Average duration in milliseconds of the last timed kernel launches, measured with HIP
- * events on the launch stream (bench.py's roofline leg).  which: 0 decode, 1 encode, 2 crc,
- * 3 pack.  Timing is recorded only between snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */
+ * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
+ * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,
+ * 3 pack, 4 decode index pass, 5 whole-stream decode pass.  Timing is recorded only between
+ * snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */
 int snappy_hip_ctx_timing(snappy_hip_ctx* ctx, int enable);
 double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* ctx, int which, uint64_t* launches);
 

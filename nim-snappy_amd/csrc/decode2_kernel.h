@@ -16,11 +16,14 @@
 //           encoder.nim:97-112) are merged back into one copy.  Copies are then resolved in
 //           rounds against a high-water mark: everything below the destination of the first
 //           unresolved copy is final, so every copy whose source ends below it can run
-//           now, one per lane; the first unresolved one can always run.  Long (merged) copies
-//           are done by all 64 lanes, overlapping ones by widening the period first.
+//           now, one per lane; the first unresolved one can always run.  Long or
+//           self-overlapping copies are done by all 64 lanes.
 //   all     flush the finished block with 16-byte stores.
 //
 // One workgroup barrier per step separates "list k is complete" from "list k is consumed".
+//
+// The inner loops are written branch-free: a lane that has nothing to store stores to a sink
+// slot instead of branching around the store (a taken branch costs more than the store).
 #pragma once
 
 #include "common.h"
@@ -30,7 +33,9 @@ namespace snappy_hip {
 
 constexpr uint32_t kD2Threads = 256;
 constexpr uint32_t kD2Ring = 4096;
-constexpr uint32_t kListCap = 1024;  // a 2 KiB chunk holds at most 1024 copy elements
+constexpr uint32_t kListCap = 1024;             // a 2 KiB chunk holds at most 1024 copy elements
+constexpr uint32_t kOutSink = kMaxBlockLen + 16; // 64 scratch dwords behind the output window,
+constexpr uint32_t kOutAlloc = kMaxBlockLen + 16 + 256 + 16;  // one per lane (no bank conflicts)
 
 struct Decode2Params {
   const uint8_t* in;
@@ -45,13 +50,35 @@ struct Decode2Params {
   const uint32_t* idx;
   uint64_t n_units;
   int unit;
+  int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
 };
 
+// value of lane-1 (0 for lane 0), without a trip through the LDS crossbar
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// Branch-free element decode (decoder.nim:42-109); no validity checks, the index pass did them.
+__device__ __forceinline__ void decode_fast(uint32_t tag, uint32_t b14, bool* is_copy, uint32_t* L,
+                                            uint32_t* size, uint32_t* hdr, uint32_t* off) {
+  const uint32_t t = tag & 3, hi6 = tag >> 2;
+  const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
+  const uint32_t m = lenlen ? (0xffffffffu >> (32 - 8 * lenlen)) : 0;
+  const uint32_t Llit = lenlen ? (b14 & m) + 1 : hi6 + 1;
+  const uint32_t L1 = 4 + (hi6 & 7), L2 = 1 + hi6;
+  const uint32_t off1 = ((tag & 0xe0) << 3) | (b14 & 0xff);
+  *is_copy = t != 0;
+  *hdr = 1 + lenlen;
+  *L = t == 0 ? Llit : (t == 1 ? L1 : L2);
+  *off = t == 1 ? off1 : (t == 2 ? (b14 & 0xffff) : b14);
+  *size = t == 0 ? 1 + lenlen + Llit : (t == 1 ? 2 : (t == 2 ? 3 : 5));
+}
+
 __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Params prm) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[kMaxBlockLen + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[kOutAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
-  __shared__ uint32_t s_cp[2][kListCap];  // dst | offset << 16
-  __shared__ uint8_t s_cl[2][kListCap];   // length 1..64
+  __shared__ uint32_t s_cp[2][kListCap + 64];  // dst | offset << 16   (+64: sink slots)
+  __shared__ uint8_t s_cl[2][kListCap + 64];   // length 1..64, 0 = skip
   __shared__ uint32_t s_cnt[2];
   __shared__ uint32_t s_err;
 
@@ -60,13 +87,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint32_t wave = tid >> 6;
   const uint64_t u = blockIdx.x;
   if (u >= prm.n_units) return;
-  if (prm.status[u] != kOk) return;       // the index pass already decided this unit
+  if (prm.status[u] != kOk) return;  // the index pass already decided this unit
   const uint32_t total = prm.out_len[u];
   if (total == 0) return;
 
   const uint8_t* in0 = prm.in + prm.in_off[u];
   uint32_t n = prm.in_len[u];
-  if (prm.unit == kUnitRaw) {             // skip the varint (validated by the index pass)
+  if (prm.unit == kUnitRaw) {  // skip the varint (validated by the index pass)
     uint32_t hdr = 0;
     while (in0[hdr] & 0x80) hdr++;
     hdr++;
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
   const uint8_t* g0 = in0 - shift;
-  const uint64_t q_end = ((uint64_t)shift + n + 15) & ~15ull;
+  const uint32_t q_end = (uint32_t)(((uint64_t)shift + n + 15) & ~15ull);
   const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
   const uint32_t n_regions = (n + kRegion - 1) / kRegion;
 
@@ -90,17 +117,39 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
   // [2048 s, 2048 s + 4096)
-  auto ring_store = [&](uint64_t q, uint4 v) {
-    const uint32_t i = (uint32_t)q & (kD2Ring - 1);
+  auto ring_store = [&](uint32_t q, uint4 v) {
+    const uint32_t i = q & (kD2Ring - 1);
     *reinterpret_cast<uint4*>(s_ring + i) = v;
     if (i == 0) *reinterpret_cast<uint4*>(s_ring + kD2Ring) = v;
   };
-  auto ring32 = [&](uint64_t q) -> uint32_t { return ld32u(s_ring + ((uint32_t)q & (kD2Ring - 1))); };
+  auto ring32 = [&](uint32_t q) -> uint32_t { return ld32u(s_ring + (q & (kD2Ring - 1))); };
+  // Stores that a lane must not perform go to its private sink dword instead of being branched
+  // around.  (One shared sink address would serialise the 64 lanes on one LDS bank.)
+  const uint32_t sink = kOutSink + lane * 4;
+  // store the low nb (0..4) bytes of v at s_out[at..]
+  auto out_store_upto4 = [&](uint32_t at, uint32_t v, uint32_t nb) {
+    st32u(s_out + (nb == 4 ? at : sink), v);
+    const bool part = nb < 4;
+    s_out[part && nb > 0 ? at : sink] = (uint8_t)v;
+    s_out[part && nb > 1 ? at + 1 : sink + 1] = (uint8_t)(v >> 8);
+    s_out[part && nb > 2 ? at + 2 : sink + 2] = (uint8_t)(v >> 16);
+  };
+  // store the first len (0..16) bytes of v[0..3] at s_out[at..]: 4 dword + 3 byte stores
+  auto out_store_upto16 = [&](uint32_t at, const uint32_t* v, uint32_t len) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) st32u(s_out + (len >= 4 * k + 4 ? at + 4 * k : sink), v[k]);
+    const uint32_t t0 = len & 12, r = len & 3;  // tail: r bytes at at+t0 (t0 = 16 needs none)
+    const uint32_t tv = t0 == 0 ? v[0] : (t0 == 4 ? v[1] : (t0 == 8 ? v[2] : v[3]));
+    const bool tl = len < 16;
+    s_out[tl && r > 0 ? at + t0 : sink] = (uint8_t)tv;
+    s_out[tl && r > 1 ? at + t0 + 1 : sink + 1] = (uint8_t)(tv >> 8);
+    s_out[tl && r > 2 ? at + t0 + 2 : sink + 2] = (uint8_t)(tv >> 16);
+  };
 
   if (wave == 0) {  // prologue: first 4 KiB of the stream
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint64_t q = (uint64_t)(lane + 64 * i) * 16;
+      const uint32_t q = (lane + 64 * i) * 16;
       if (q < q_end) ring_store(q, *reinterpret_cast<const uint4*>(g0 + q));
     }
   }
@@ -110,86 +159,73 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     if (wave == 0 && s < n_chunks) {
       // =================================== front end ===========================================
       const uint32_t buf = s & 1;
-      const uint64_t c0 = (uint64_t)s * kChunk;
-      // loads for the step after next, consumed at the end of this step
+      const uint32_t c0 = s * kChunk;
+      // loads for the step after next, landed at the end of this step
       uint4 pre[2];
-      uint64_t pq[2];
+      uint32_t pq[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        pq[i] = c0 + kD2Ring + (uint64_t)(lane + 64 * i) * 16;
+        pq[i] = c0 + kD2Ring + (lane + 64 * i) * 16;
         pre[i] = make_uint4(0, 0, 0, 0);
         if (pq[i] < q_end) pre[i] = *reinterpret_cast<const uint4*>(g0 + pq[i]);
       }
       const uint32_t r = s * 64 + lane;
       const uint32_t ie = r < n_regions ? idx[r] : kIdxNone;
       const uint32_t e_off = ie & 63;
-      const uint32_t ncopy = (ie >> 6) & 31;
+      const bool had = e_off != kIdxNone;
+      const uint32_t ncopy = had ? (ie >> 6) & 31 : 0;
       uint32_t dst = ie >> 11;
       uint32_t ctot;
-      uint32_t slot = wave_excl_scan(e_off == kIdxNone ? 0 : ncopy, lane, &ctot);
+      uint32_t slot = wave_excl_scan(ncopy, lane, &ctot);
       if (lane == 0) s_cnt[buf] = ctot;
-      const uint32_t slot_end = slot + (e_off == kIdxNone ? 0 : ncopy);
-      const uint32_t dst0 = dst;
 
-      const uint64_t rs = c0 + (uint64_t)lane * kRegion;
-      uint64_t pos = rs + e_off;
-      bool live = e_off != kIdxNone && pos < n;
-      bool big = false;          // a literal longer than 64 bytes ends my region: done below
-      uint32_t big_dst = 0, big_len = 0;
-      uint64_t big_src = 0;
+      const uint32_t rs = c0 + lane * kRegion;
+      const uint32_t r_end = rs + kRegion < n ? rs + kRegion : n;
+      uint32_t pos = rs + e_off;
+      bool live = had && pos < n && !(prm.dbg & 4);
+      bool big = false;  // a literal longer than 64 bytes ends my region: done below
+      uint32_t big_dst = 0, big_len = 0, big_src = 0;
       bool bad = false;
       while (ballot(live)) {
-        if (live) {
-          const uint64_t q = pos + shift;
-          const uint32_t w0 = ring32(q), w1 = ring32(q + 4);
-          const uint32_t tag = w0 & 0xff;
-          const uint32_t b14 = (w0 >> 8) | (w1 << 24);
-          bool is_copy;
-          uint32_t L, size, hdr, off;
-          decode_element(tag, b14, 0xffffffffu, &is_copy, &L, &size, &hdr, &off);
-          if (is_copy) {
-            const bool bad_off = off == 0 || off > dst;  // decoder.nim:112
-            bad = bad || bad_off;
-            s_cp[buf][slot] = bad_off ? (dst | (1u << 16)) : (dst | (off << 16));
-            s_cl[buf][slot] = bad_off ? 0 : (uint8_t)L;  // length 0 = skipped by the resolver
-            slot++;
-          } else if (L <= 64) {
-            const uint64_t qs = q + hdr;
+        const uint32_t q = pos + shift;
+        const uint32_t w0 = ring32(q), w1 = ring32(q + 4);
+        const uint32_t b14 = (w0 >> 8) | (w1 << 24);
+        bool is_copy;
+        uint32_t L, size, hdr, off;
+        decode_fast(w0 & 0xff, b14, &is_copy, &L, &size, &hdr, &off);
+        const bool cpy = live && is_copy;
+        const bool lit = live && !is_copy;
+        // ---- copy: append to the list (sink slot when this lane has no copy) ------------------
+        const bool bad_off = cpy && (off == 0 || off > dst);  // decoder.nim:112
+        bad = bad || bad_off;
+        const uint32_t sl = cpy ? slot : kListCap + lane;
+        s_cp[buf][sl] = bad_off ? (dst | (1u << 16)) : (dst | (off << 16));
+        s_cl[buf][sl] = bad_off ? 0 : (uint8_t)L;  // length 0 = skipped by the resolver
+        slot += cpy ? 1 : 0;
+        // ---- literal: payload of up to 16 bytes here, up to 64 in the rare loop below -----------
+        const uint32_t qs = q + hdr;
+        const uint32_t Lw = (lit && L <= 64 && !(prm.dbg & 1)) ? L : 0;  // bytes this lane writes
+        {
+          uint32_t v[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k += 4) {
-              if (k < L) {
-                const uint32_t v = ring32(qs + k);
-                const uint32_t nb = L - k < 4 ? L - k : 4;
-                if (nb == 4) {
-                  st32u(s_out + dst + k, v);
-                } else {
-                  s_out[dst + k] = (uint8_t)v;
-                  if (nb > 1) s_out[dst + k + 1] = (uint8_t)(v >> 8);
-                  if (nb > 2) s_out[dst + k + 2] = (uint8_t)(v >> 16);
-                }
-              }
-            }
-            for (uint32_t k = 16; k < L; k += 4) {
-              const uint32_t v = ring32(qs + k);
-              const uint32_t nb = L - k < 4 ? L - k : 4;
-              if (nb == 4) {
-                st32u(s_out + dst + k, v);
-              } else {
-                s_out[dst + k] = (uint8_t)v;
-                if (nb > 1) s_out[dst + k + 1] = (uint8_t)(v >> 8);
-                if (nb > 2) s_out[dst + k + 2] = (uint8_t)(v >> 16);
-              }
-            }
-          } else {
-            big = true;
-            big_dst = dst;
-            big_len = L;
-            big_src = pos + hdr;
-          }
-          dst += L;
-          pos += size;
-          live = pos < rs + kRegion && pos < n;
+          for (uint32_t k = 0; k < 4; k++) v[k] = ring32(qs + 4 * k);
+          out_store_upto16(dst, v, Lw < 16 ? Lw : 16);
         }
+        if (ballot(Lw > 16)) {
+          for (uint32_t k = 16; k < 64; k += 4) {
+            const uint32_t v = ring32(qs + k);
+            out_store_upto4(dst + k, v, Lw > k ? (Lw - k < 4 ? Lw - k : 4) : 0);
+          }
+        }
+        if (lit && L > 64) {
+          big = true;
+          big_dst = dst;
+          big_len = L;
+          big_src = pos + hdr;
+        }
+        dst += live ? L : 0;
+        pos += live ? size : 0;
+        live = live && pos < r_end;
       }
       // long literals: whole wave, straight from HBM (at most one per region)
       uint64_t bigs = ballot(big);
@@ -198,136 +234,107 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         bigs &= bigs - 1;
         const uint32_t eL = readlane(big_len, e);
         const uint32_t ed = readlane(big_dst, e);
-        const uint64_t es = ((uint64_t)readlane((uint32_t)(big_src >> 32), e) << 32) |
-                            readlane((uint32_t)big_src, e);
-        for (uint32_t i = lane * 4; i < eL; i += 256) {
-          if (i + 4 <= eL) {
-            st32u(s_out + ed + i, ld32u(in0 + es + i));
-          } else {
-            for (uint32_t k = i; k < eL; k++) s_out[ed + k] = in0[es + k];
+        const uint32_t es = readlane(big_src, e);
+        // 16 bytes per lane and pass, four passes in flight
+        const uint32_t body = eL & ~15u;
+        for (uint32_t i = lane * 16; i < body; i += 4 * 1024) {
+          uint4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (i + j * 1024 < body) __builtin_memcpy(&v[j], in0 + es + i + j * 1024, 16);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (i + j * 1024 < body) {
+              st32u(s_out + ed + i + j * 1024, v[j].x);
+              st32u(s_out + ed + i + j * 1024 + 4, v[j].y);
+              st32u(s_out + ed + i + j * 1024 + 8, v[j].z);
+              st32u(s_out + ed + i + j * 1024 + 12, v[j].w);
+            }
           }
         }
+        if (body + lane < eL) s_out[ed + body + lane] = in0[es + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
-      {  // DEBUG consistency checks of the index against the walk
-        const bool had = e_off != kIdxNone;
-        if (ballot(had && slot != slot_end) && lane == 0) atomicOr(&s_err, 2u);
-        // my final dst must be the first dst of the next region that has an entry
-        const uint64_t hm = ballot(had);
-        const uint64_t later = lane == 63 ? 0 : hm & ~((2ull << lane) - 1);
-        const uint32_t nx = later ? ctz64(later) : 64;
-        const uint32_t nd = __shfl(dst0, nx & 63, 64);
-        if (ballot(had && nx != 64 && nd != dst) && lane == 0) atomicOr(&s_err, 4u);
-      }
       // the ring slots of this chunk are free now: land the prefetched 2 KiB
 #pragma unroll
       for (int i = 0; i < 2; i++)
         if (pq[i] < q_end) ring_store(pq[i], pre[i]);
-    } else if (wave == 1 && s >= 1) {
+    } else if (wave == 1 && s >= 1 && !(prm.dbg & 2)) {
       // =================================== resolver ==============================================
       const uint32_t buf = (s - 1) & 1;
       const uint32_t count = s_cnt[buf];
       for (uint32_t b0 = 0; b0 < count; b0 += 64) {
         const uint32_t i = b0 + lane;
         const uint32_t len = i < count ? s_cl[buf][i] : 0;
+        const uint32_t e = s_cp[buf][i];
         const bool act = len != 0;
-        const uint32_t e = act ? s_cp[buf][i] : 0;
         const uint32_t dst = e & 0xffff, off = e >> 16;
+        const uint32_t src = act ? dst - off : 0;
         // merge runs: same offset, destination continues the previous copy
-        const uint32_t p_e = __shfl_up(e, 1, 64), p_len = __shfl_up(len, 1, 64);
-        const bool cont = act && lane > 0 && (p_e >> 16) == off && (p_e & 0xffff) + p_len == dst;
+        const uint32_t p_e = lane_prev(e), p_len = lane_prev(len);
+        const bool cont = act && p_len != 0 && (p_e >> 16) == off && (p_e & 0xffff) + p_len == dst;
         const uint64_t heads = ballot(act && !cont);
-        uint32_t tot;
-        const uint32_t excl = wave_excl_scan(len, lane, &tot);
-        const uint64_t later = lane == 63 ? 0 : heads & ~((2ull << lane) - 1);
-        const uint32_t nxt = later ? ctz64(later) : 64;
-        const uint32_t nxt_excl = __shfl(excl, nxt & 63, 64);
-        const uint32_t mlen = (nxt == 64 ? tot : nxt_excl) - excl;  // merged length (heads only)
-        const uint32_t src = dst - off;
+        uint32_t mlen = len;
+        if (ballot(cont)) {  // rare on text, the rule on run-like data
+          uint32_t tot;
+          const uint32_t excl = wave_excl_scan(len, lane, &tot);
+          const uint64_t later = lane == 63 ? 0 : heads & ~((2ull << lane) - 1);
+          const uint32_t nxt = later ? ctz64(later) : 64;
+          const uint32_t nxt_excl = __shfl(excl, nxt & 63, 64);
+          mlen = (nxt == 64 ? tot : nxt_excl) - excl;  // merged length (meaningful on heads)
+        }
+        // per-lane path: short and not self-overlapping
+        const bool simple = mlen <= 16 && off >= mlen;
+        const uint64_t simple_m = ballot(simple);
 
         uint64_t pending = heads;
         while (pending) {
           const uint32_t first = ctz64(pending);
-          const uint32_t fL = readlane(mlen, first);
-          const uint32_t fd = readlane(dst, first);
-          if (fL > 16) {
-            // ---- long copy by the whole wave -------------------------------------------------
+          const uint32_t fd = readlane(dst, first);  // everything below fd is final
+          if (!((simple_m >> first) & 1)) {
+            // ---- long or self-overlapping copy: the whole wave -------------------------------
+            const uint32_t fL = readlane(mlen, first);
             const uint32_t foff = readlane(off, first);
             const uint32_t fs = fd - foff;
-            uint32_t done = 0;
-            uint32_t period = foff;
-            if (foff < 256) {
-              // overlap: out[fd+i] = out[fs + i mod foff]; write up to 512 bytes bytewise, after
-              // which a multiple of the period that is >= 256 serves as the copy distance
-              const uint32_t rcp = 65536u / foff + 1;
-              const uint32_t head_len = fL < 512 ? fL : 512;
-              for (uint32_t i = lane; i < head_len; i += 64) {
-                uint32_t j = i;
-                if (foff <= i) {
-                  // i < 512, foff < 256: (i*rcp)>>16 == i/foff whenever i*foff < 65536... use
-                  // the safe form for the upper half
-                  uint32_t qd = (i * rcp) >> 16;
-                  if (qd * foff > i) qd--;
-                  j = i - qd * foff;
-                  if (j >= foff) j -= foff;
+            if (fL <= 256 && foff >= fL) {  // one pass, no overlap
+              const uint32_t at = lane * 4;
+              const uint32_t v = ld32u(s_out + fs + (at < fL ? at : 0));
+              out_store_upto4(fd + at, v, fL > at ? (fL - at < 4 ? fL - at : 4) : 0);
+            } else {
+              uint32_t done = 0, period = foff;
+              if (foff < 256) {
+                // overlap: out[fd+i] = out[fs + i mod foff].  Bytewise for the first 512 bytes;
+                // after that a multiple of the period that is >= 256 is the copy distance.
+                const uint32_t head_len = fL < 512 ? fL : 512;
+                uint32_t j = lane % foff;  // (lane + 64 t) mod foff, kept incrementally
+                const uint32_t inc = 64 % foff;
+                for (uint32_t i = lane; i < head_len; i += 64) {
+                  s_out[fd + i] = s_out[fs + j];
+                  j += inc;
+                  j = j >= foff ? j - foff : j;
                 }
-                s_out[fd + i] = s_out[fs + j];
+                wave_fence();
+                done = head_len;
+                period = foff * ((255 + foff) / foff);  // multiple of foff in [256, 511]
               }
-              wave_fence();
-              done = head_len;
-              period = foff * ((255 + foff) / foff);  // multiple of foff in [256, 511]
-            }
-            for (uint32_t i = done + lane * 4; i < fL; i += 256) {
-              // period >= 256: the 256 bytes of one pass only read bytes of earlier passes
-              const uint32_t v = ld32u(s_out + fd + i - period);
-              const uint32_t nb = fL - i < 4 ? fL - i : 4;
-              if (nb == 4) {
-                st32u(s_out + fd + i, v);
-              } else {
-                s_out[fd + i] = (uint8_t)v;
-                if (nb > 1) s_out[fd + i + 1] = (uint8_t)(v >> 8);
-                if (nb > 2) s_out[fd + i + 2] = (uint8_t)(v >> 16);
+              for (uint32_t i = done + lane * 4; i < fL; i += 256) {
+                // period >= 256: the 256 bytes of one pass only read bytes of earlier passes
+                const uint32_t v = ld32u(s_out + fd + i - period);
+                out_store_upto4(fd + i, v, fL - i < 4 ? fL - i : 4);
+                wave_fence();
               }
-              wave_fence();
             }
             pending &= pending - 1;
+            wave_fence();
             continue;
           }
           // ---- short copies: one per lane, everything whose source is final ------------------
-          const bool pend_me = (pending >> lane) & 1;
-          const bool ready = pend_me && mlen <= 16 && (lane == first || src + mlen <= fd);
-          if (ready) {
-            if (off >= mlen) {
-              uint32_t v[4];
+          const bool ready = ((pending >> lane) & 1) && simple && (lane == first || src + mlen <= fd);
+          const uint32_t Lw = ready ? mlen : 0;
+          uint32_t v[4];
 #pragma unroll
-              for (uint32_t k = 0; k < 4; k++)
-                if (4 * k < mlen) v[k] = ld32u(s_out + src + 4 * k);
-#pragma unroll
-              for (uint32_t k = 0; k < 4; k++) {
-                if (4 * k < mlen) {
-                  const uint32_t nb = mlen - 4 * k < 4 ? mlen - 4 * k : 4;
-                  if (nb == 4) {
-                    st32u(s_out + dst + 4 * k, v[k]);
-                  } else {
-                    s_out[dst + 4 * k] = (uint8_t)v[k];
-                    if (nb > 1) s_out[dst + 4 * k + 1] = (uint8_t)(v[k] >> 8);
-                    if (nb > 2) s_out[dst + 4 * k + 2] = (uint8_t)(v[k] >> 16);
-                  }
-                }
-              }
-            } else {  // overlapping short copy: pattern of `off` bytes
-              uint32_t j = 0;
-              uint32_t v[16];
-#pragma unroll
-              for (uint32_t k = 0; k < 16; k++) {
-                if (k < mlen) v[k] = s_out[src + j];
-                j = j + 1 == off ? 0 : j + 1;
-              }
-#pragma unroll
-              for (uint32_t k = 0; k < 16; k++)
-                if (k < mlen) s_out[dst + k] = (uint8_t)v[k];
-            }
-          }
+          for (uint32_t k = 0; k < 4; k++) v[k] = ld32u(s_out + src + 4 * k);
+          out_store_upto16(dst, v, Lw);
           pending &= ~ballot(ready);
           wave_fence();
         }
@@ -338,9 +345,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   // ---- flush ------------------------------------------------------------------------------------
   if (s_err) {
-    if (tid == 0) prm.status[u] = s_err == 1 ? kInvalidInput : 1000 + s_err;
-    if (s_err == 1) return;
+    if (tid == 0) prm.status[u] = kInvalidInput;
+    return;
   }
+  if (prm.dbg & 8) return;
   if (((uintptr_t)gout & 15) == 0) {
     for (uint32_t i = tid * 16; i < total; i += kD2Threads * 16) {
       if (i + 16 <= total) {

@@ -87,8 +87,8 @@ struct snappy_hip_ctx {
     int which;
   };
   std::vector<Timed> timed;
-  double ms_sum[4] = {0, 0, 0, 0};
-  uint64_t ms_cnt[4] = {0, 0, 0, 0};
+  double ms_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t ms_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -226,7 +226,7 @@ extern "C" int snappy_hip_ctx_timing(snappy_hip_ctx* c, int enable) {
       (void)hipEventDestroy(t.b);
     }
     c->timed.clear();
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 8; i++) {
       c->ms_sum[i] = 0;
       c->ms_cnt[i] = 0;
     }
@@ -245,7 +245,7 @@ extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_
     (void)hipEventDestroy(t.b);
   }
   c->timed.clear();
-  if (which < 0 || which > 3) return 0;
+  if (which < 0 || which > 7) return 0;
   if (launches) *launches = c->ms_cnt[which];
   return c->ms_cnt[which] ? c->ms_sum[which] / (double)c->ms_cnt[which] : 0.0;
 }
@@ -420,8 +420,11 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.idx = (const uint32_t*)d_idx;
     dp.n_units = n_units;
     dp.unit = unit;
-    LaunchTimer lt(c, s, 0);
-    hipLaunchKernelGGL(index_units_kernel, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+    if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
+    {
+      LaunchTimer lt(c, s, 4);
+      hipLaunchKernelGGL(index_units_kernel, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+    }
     if (getenv("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
       uint32_t* d_rep;
       HIP_TRY(hipMalloc((void**)&d_rep, n_units * 16));
@@ -439,10 +442,15 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       fprintf(stderr, "index verify: %d units with a mismatch\n", shown);
       (void)hipFree(d_rep);
     }
-    hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+    {
+      LaunchTimer lt(c, s, 0);
+      hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+    }
   }
-  if (stream_pass)
+  if (stream_pass) {
+    LaunchTimer lt(c, s, 5);
     hipLaunchKernelGGL(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+  }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
 }
