@@ -11,7 +11,12 @@
 //           elements, in stream order, to a list in LDS (slot = wave prefix sum of the
 //           per-region copy counts).  The next 2 KiB of the stream and its index entries are
 //           in flight from HBM while the current ones are processed.
-//   wave 1  "resolver": consumes the PREVIOUS step's copy list 64 elements at a time.  Runs of
+//   waves 2,3 "far copies": a copy of the PREVIOUS step's list whose source ends below that
+//           chunk's first output byte depends on nothing unresolved (all earlier lists are
+//           done), so these two waves execute all such copies in parallel, alternate batches,
+//           and cross them off the list (62 % of the copies of text, 44 % of html).
+//   wave 1  "resolver": waits for them, then consumes what is left of the PREVIOUS step's list,
+//           64 elements at a time.  Runs of
 //           consecutive copies with one offset (how the encoder splits long matches,
 //           encoder.nim:97-112) are merged back into one copy.  Copies are then resolved in
 //           rounds against a high-water mark: everything below the destination of the first
@@ -51,6 +56,7 @@ struct Decode2Params {
   uint64_t n_units;
   int unit;
   int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
+  unsigned long long* stats;  // DEBUG counters (nullptr = off)
 };
 
 // value of lane-1 (0 for lane 0), without a trip through the LDS crossbar
@@ -80,6 +86,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   __shared__ uint32_t s_cp[2][kListCap + 64];  // dst | offset << 16   (+64: sink slots)
   __shared__ uint8_t s_cl[2][kListCap + 64];   // length 1..64, 0 = skip
   __shared__ uint32_t s_cnt[2];
+  __shared__ uint32_t s_xdone[2];  // far-copy waves finished with list k
+  __shared__ uint32_t s_near[2][2];  // near copies left in each half of list k after compaction
+  __shared__ uint32_t s_mode[2];     // list k is resolved through the pending-byte bitmap
+  // One bit per output byte (position mod 8192): set while a copy that produces the byte is
+  // still unresolved.  A copy may run as soon as no bit of its source range is set.
+  __shared__ unsigned long long s_pend[128];
   __shared__ uint32_t s_err;
 
   const uint32_t tid = threadIdx.x;
@@ -113,7 +125,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_err = 0;
     s_cnt[0] = 0;
     s_cnt[1] = 0;
+    s_xdone[0] = 0;
+    s_xdone[1] = 0;
+    s_mode[0] = 0;
+    s_mode[1] = 0;
   }
+  for (uint32_t i = tid; i < 128; i += kD2Threads) s_pend[i] = 0;
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
   // [2048 s, 2048 s + 4096)
@@ -146,6 +163,49 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_out[tl && r > 2 ? at + t0 + 2 : sink + 2] = (uint8_t)(tv >> 16);
   };
 
+  // Copy L (0 = nothing, <= 64) bytes to s_out[dst..].  rd(k) returns the k-th ALIGNED dword of
+  // the source counted from the dword that holds its first byte; sh = source address & 3.
+  // Unaligned LDS dword accesses cost ~10-20x an aligned one on gfx950 (tools/probes/
+  // lds_rates.hip), so sources are read as aligned dwords and re-aligned with a funnel shift,
+  // and the destination is written bytewise.
+  auto lean_copy = [&](uint32_t dst, auto rd, uint32_t sh, uint32_t L) {
+    const uint32_t sh8 = sh * 8;
+    uint32_t s0 = rd(0u), s1 = rd(1u), s2 = rd(2u);
+    uint32_t v0 = __funnelshift_r(s0, s1, sh8), v1 = __funnelshift_r(s1, s2, sh8);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) s_out[L > j ? dst + j : sink + j] = (uint8_t)(v0 >> (8 * j));
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? dst + 4 + j : sink + j] = (uint8_t)(v1 >> (8 * j));
+    for (uint32_t k = 8; ballot(L > k); k += 8) {  // longer elements: 8 more bytes per trip
+      s0 = s2;
+      s1 = rd(k / 4 + 1);
+      s2 = rd(k / 4 + 2);
+      v0 = __funnelshift_r(s0, s1, sh8);
+      v1 = __funnelshift_r(s1, s2, sh8);
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? dst + k + j : sink + j] = (uint8_t)(v0 >> (8 * j));
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++)
+        s_out[L > k + 4 + j ? dst + k + 4 + j : sink + j] = (uint8_t)(v1 >> (8 * j));
+    }
+  };
+  auto out_al = [&](uint32_t a) -> uint32_t {  // aligned dword that holds s_out[a]
+    return *reinterpret_cast<const uint32_t*>(s_out + (a & ~3u));
+  };
+  auto ring_al = [&](uint32_t q) -> uint32_t {  // aligned dword that holds stream byte q - shift
+    return *reinterpret_cast<const uint32_t*>(s_ring + (q & (kD2Ring - 1) & ~3u));
+  };
+  // pending-byte bitmap as 256 dwords; a run of len bits at pos touches up to three of them
+  uint32_t* const pw = reinterpret_cast<uint32_t*>(s_pend);
+  auto bits_make = [&](uint32_t pos, uint32_t len, uint32_t* d0, uint32_t* d1, uint32_t* d2) {
+    const uint32_t sh = pos & 31;
+    const unsigned long long m = len >= 64 ? ~0ull : ((1ull << len) - 1);
+    const unsigned long long lo = m << sh;
+    *d0 = (uint32_t)lo;
+    *d1 = (uint32_t)(lo >> 32);
+    *d2 = sh ? (uint32_t)(m >> (64 - sh)) : 0;
+  };
+
   if (wave == 0) {  // prologue: first 4 KiB of the stream
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -154,6 +214,14 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     }
   }
   __syncthreads();
+
+  // index entries of the current and the next chunk (front-end wave; loaded two steps ahead)
+  uint32_t ie_cur = kIdxNone, ie_nxt = kIdxNone;
+  if (wave == 0) {
+    ie_cur = lane < n_regions ? idx[lane] : kIdxNone | (total << 11);
+    ie_nxt = 64 + lane < n_regions ? idx[64 + lane] : kIdxNone | (total << 11);
+  }
+  uint32_t cprev = 0;  // output position where the previous chunk starts
 
   for (uint32_t s = 0; s <= n_chunks; s++) {
     if (wave == 0 && s < n_chunks) {
@@ -169,15 +237,27 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         pre[i] = make_uint4(0, 0, 0, 0);
         if (pq[i] < q_end) pre[i] = *reinterpret_cast<const uint4*>(g0 + pq[i]);
       }
-      const uint32_t r = s * 64 + lane;
-      const uint32_t ie = r < n_regions ? idx[r] : kIdxNone;
+      const uint32_t r2 = (s + 2) * 64 + lane;
+      const uint32_t ie_far = r2 < n_regions ? idx[r2] : kIdxNone | (total << 11);  // for step s+2
+      const uint32_t ie = ie_cur;
       const uint32_t e_off = ie & 63;
       const bool had = e_off != kIdxNone;
       const uint32_t ncopy = had ? (ie >> 6) & 31 : 0;
       uint32_t dst = ie >> 11;
       uint32_t ctot;
       uint32_t slot = wave_excl_scan(ncopy, lane, &ctot);
-      if (lane == 0) s_cnt[buf] = ctot;
+      if (lane == 0) {
+        s_cnt[buf] = ctot;
+        s_xdone[buf] = 0;
+      }
+      const uint32_t cbase = readlane(dst, 0);           // output position where this chunk starts
+      const uint32_t cnext = readlane(ie_nxt >> 11, 0);  // ... and where the next one starts
+      // bitmap mode needs this chunk and the previous one to fit the 8192-position window
+      const bool bm = cnext - cprev <= 8192 - 256;
+      if (lane == 0) s_mode[buf] = bm ? 1 : 0;
+      cprev = cbase;
+      ie_cur = ie_nxt;
+      ie_nxt = ie_far;
 
       const uint32_t rs = c0 + lane * kRegion;
       const uint32_t r_end = rs + kRegion < n ? rs + kRegion : n;
@@ -186,9 +266,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       bool big = false;  // a literal longer than 64 bytes ends my region: done below
       uint32_t big_dst = 0, big_len = 0, big_src = 0;
       bool bad = false;
+      uint32_t st_trips = 0;
       while (ballot(live)) {
+        st_trips++;
         const uint32_t q = pos + shift;
-        const uint32_t w0 = ring32(q), w1 = ring32(q + 4);
+        const uint32_t t0 = ring_al(q), t1 = ring_al(q + 4), t2 = ring_al(q + 8);
+        const uint32_t w0 = __funnelshift_r(t0, t1, (q & 3) * 8), w1 = __funnelshift_r(t1, t2, (q & 3) * 8);
         const uint32_t b14 = (w0 >> 8) | (w1 << 24);
         bool is_copy;
         uint32_t L, size, hdr, off;
@@ -200,23 +283,22 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         bad = bad || bad_off;
         const uint32_t sl = cpy ? slot : kListCap + lane;
         s_cp[buf][sl] = bad_off ? (dst | (1u << 16)) : (dst | (off << 16));
-        s_cl[buf][sl] = bad_off ? 0 : (uint8_t)L;  // length 0 = skipped by the resolver
+        // bit 7: source ends below this chunk's output = independent of every unresolved copy
+        const uint32_t far = (dst - off + L <= cbase) ? 0x80u : 0u;
+        s_cl[buf][sl] = bad_off ? 0 : (uint8_t)(L | far);  // length 0 = nothing to do
         slot += cpy ? 1 : 0;
+        if (bm) {  // mark the bytes this copy will produce as pending
+          uint32_t d0, d1, d2;
+          bits_make(dst, (cpy && !bad_off) ? L : 0, &d0, &d1, &d2);
+          const uint32_t w = (dst & 8191) >> 5;
+          atomicOr(pw + w, d0);
+          atomicOr(pw + ((w + 1) & 255), d1);
+          if (ballot(d2 != 0)) atomicOr(pw + ((w + 2) & 255), d2);
+        }
         // ---- literal: payload of up to 16 bytes here, up to 64 in the rare loop below -----------
         const uint32_t qs = q + hdr;
         const uint32_t Lw = (lit && L <= 64 && !(prm.dbg & 1)) ? L : 0;  // bytes this lane writes
-        {
-          uint32_t v[4];
-#pragma unroll
-          for (uint32_t k = 0; k < 4; k++) v[k] = ring32(qs + 4 * k);
-          out_store_upto16(dst, v, Lw < 16 ? Lw : 16);
-        }
-        if (ballot(Lw > 16)) {
-          for (uint32_t k = 16; k < 64; k += 4) {
-            const uint32_t v = ring32(qs + k);
-            out_store_upto4(dst + k, v, Lw > k ? (Lw - k < 4 ? Lw - k : 4) : 0);
-          }
-        }
+        lean_copy(dst, [&](uint32_t k) { return ring_al(qs + 4 * k); }, qs & 3, Lw);
         if (lit && L > 64) {
           big = true;
           big_dst = dst;
@@ -255,17 +337,123 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (body + lane < eL) s_out[ed + body + lane] = in0[es + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
+      if (prm.stats && lane == 0) {
+        atomicAdd(&prm.stats[4], (unsigned long long)st_trips);
+        atomicAdd(&prm.stats[5], 1ull);
+        atomicAdd(&prm.stats[6], (unsigned long long)(bm ? 1 : 0));
+      }
       // the ring slots of this chunk are free now: land the prefetched 2 KiB
 #pragma unroll
       for (int i = 0; i < 2; i++)
         if (pq[i] < q_end) ring_store(pq[i], pre[i]);
-    } else if (wave == 1 && s >= 1 && !(prm.dbg & 2)) {
-      // =================================== resolver ==============================================
+    } else if (wave >= 1 && s >= 1 && s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
+      // =================================== resolver pool ==========================================
+      // Three waves share the previous step's list (batches round-robin).  Dependencies are
+      // exact: a copy runs when no byte of its source is still pending, whichever wave owns the
+      // copies it waits for.  The lowest unresolved copy of the list is always runnable and its
+      // owner is always working on its batch, so the pool cannot dead-lock.
       const uint32_t buf = (s - 1) & 1;
       const uint32_t count = s_cnt[buf];
-      for (uint32_t b0 = 0; b0 < count; b0 += 64) {
+      for (uint32_t b0 = (wave - 1) * 64; b0 < count; b0 += 192) {
         const uint32_t i = b0 + lane;
-        const uint32_t len = i < count ? s_cl[buf][i] : 0;
+        const uint32_t lf = i < count ? s_cl[buf][i] : 0;
+        const uint32_t e = s_cp[buf][i];
+        const uint32_t len = lf & 0x7f;
+        const bool act = len != 0;
+        const bool far = (lf & 0x80) != 0;
+        const uint32_t dst = e & 0xffff, off = e >> 16;
+        const uint32_t src = act ? dst - off : 0;
+        const bool ovl = act && off < len;  // self-overlapping: the source is the `off` bytes below dst
+        uint32_t m0, m1, m2, q0, q1, q2;
+        bits_make(dst, len, &m0, &m1, &m2);             // the bytes I produce
+        const uint32_t slen = ovl ? off : len;
+        bits_make(src, slen, &q0, &q1, &q2);            // the bytes I need
+        const uint32_t bw = (dst & 8191) >> 5, sw = (src & 8191) >> 5;
+        const bool wide = ballot(m2 != 0 || q2 != 0) != 0;
+        uint64_t pend = ballot(act);
+        uint32_t st_rounds = 0, st_spins = 0;
+        while (pend) {
+          st_rounds++;
+          uint32_t busy =
+              (__hip_atomic_load(pw + sw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q0) |
+              (__hip_atomic_load(pw + ((sw + 1) & 255), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q1);
+          if (wide)
+            busy |= __hip_atomic_load(pw + ((sw + 2) & 255), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q2;
+          const bool rdy = ((pend >> lane) & 1) && (far || busy == 0);
+          const uint64_t rm = ballot(rdy);
+          if (rm == 0) {  // everything left waits for another wave
+            st_spins++;
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          lean_copy(dst, [&](uint32_t k) { return out_al(src + 4 * k); }, src & 3, (rdy && !ovl) ? len : 0);
+          if (ballot(rdy && ovl)) {  // rare: replicate the pattern of `off` bytes
+            if (rdy && ovl) {
+              uint32_t j = 0;
+              for (uint32_t k = 0; k < len; k++) {
+                s_out[dst + k] = s_out[src + j];
+                j = j + 1 == off ? 0 : j + 1;
+              }
+            }
+          }
+          wave_fence();
+          __hip_atomic_fetch_and(pw + bw, rdy ? ~m0 : ~0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_and(pw + ((bw + 1) & 255), rdy ? ~m1 : ~0u, __ATOMIC_RELEASE,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (wide)
+            __hip_atomic_fetch_and(pw + ((bw + 2) & 255), rdy ? ~m2 : ~0u, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          pend &= ~rm;
+        }
+        if (prm.stats && lane == 0) {
+          atomicAdd(&prm.stats[0], (unsigned long long)st_rounds);
+          atomicAdd(&prm.stats[1], (unsigned long long)st_spins);
+          atomicAdd(&prm.stats[2], 1ull);
+          atomicAdd(&prm.stats[3], (unsigned long long)__builtin_popcountll(ballot(act)));
+        }
+      }
+    } else if (wave >= 2 && s >= 1 && !(prm.dbg & 2)) {
+      // =================================== far copies ============================================
+      const uint32_t buf = (s - 1) & 1;
+      const uint32_t count = s_cnt[buf];
+      // each of the two waves owns one contiguous half of the list: it executes the far copies
+      // and compacts the remaining (near) ones in place, in order, at the front of its half
+      const uint32_t half = ((count + 127) / 128) * 64;
+      const uint32_t seg0 = (wave - 2) * half;
+      const uint32_t seg1 = seg0 + half < count ? seg0 + half : count;
+      uint32_t wpos = seg0;
+      for (uint32_t b0 = seg0; b0 < seg1; b0 += 64) {
+        const uint32_t i = b0 + lane;
+        const uint32_t lf = i < seg1 ? s_cl[buf][i] : 0;
+        const uint32_t e = s_cp[buf][i];
+        const bool far = (lf & 0x80) != 0;
+        const bool near = lf != 0 && !far;
+        const uint32_t len = lf & 0x7f;
+        const uint32_t dst = e & 0xffff;
+        const uint32_t src = far ? dst - (e >> 16) : 0;
+        lean_copy(dst, [&](uint32_t k) { return out_al(src + 4 * k); }, src & 3, far ? len : 0);
+        const uint64_t nm = ballot(near);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(nm & ((1ull << lane) - 1));
+        wave_fence();  // all reads of this batch are done before its slots are reused
+        const uint32_t to = near ? wpos + rank : kListCap + lane;
+        s_cp[buf][to] = e;
+        s_cl[buf][to] = (uint8_t)len;
+        wpos += (uint32_t)__builtin_popcountll(nm);
+      }
+      if (lane == 0) s_near[buf][wave - 2] = wpos - seg0;
+      wave_fence();
+      if (lane == 0) atomicAdd(&s_xdone[buf], 1u);
+    } else if (wave == 1 && s >= 1 && !(prm.dbg & 2)) {
+      // =================================== resolver ==============================================
+      while (__hip_atomic_load(&s_xdone[(s - 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2)
+        __builtin_amdgcn_s_sleep(2);
+      wave_fence();
+      const uint32_t buf = (s - 1) & 1;
+      const uint32_t half = ((s_cnt[buf] + 127) / 128) * 64;
+      for (uint32_t seg = 0; seg < 2; seg++)
+      for (uint32_t b0 = seg * half, count = seg * half + s_near[buf][seg]; b0 < count; b0 += 64) {
+        const uint32_t i = b0 + lane;
+        const uint32_t len = i < count ? (s_cl[buf][i] & 0x7fu) : 0;
         const uint32_t e = s_cp[buf][i];
         const bool act = len != 0;
         const uint32_t dst = e & 0xffff, off = e >> 16;
@@ -330,11 +518,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           }
           // ---- short copies: one per lane, everything whose source is final ------------------
           const bool ready = ((pending >> lane) & 1) && simple && (lane == first || src + mlen <= fd);
-          const uint32_t Lw = ready ? mlen : 0;
-          uint32_t v[4];
-#pragma unroll
-          for (uint32_t k = 0; k < 4; k++) v[k] = ld32u(s_out + src + 4 * k);
-          out_store_upto16(dst, v, Lw);
+          lean_copy(dst, [&](uint32_t k) { return out_al(src + 4 * k); }, src & 3, ready ? mlen : 0);
           pending &= ~ballot(ready);
           wave_fence();
         }

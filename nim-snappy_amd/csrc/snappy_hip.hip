@@ -421,6 +421,12 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.n_units = n_units;
     dp.unit = unit;
     if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
+    unsigned long long* d_stats = nullptr;
+    if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+      HIP_TRY(hipMalloc((void**)&d_stats, 64));
+      HIP_TRY(hipMemsetAsync(d_stats, 0, 64, s));
+      dp.stats = d_stats;
+    }
     {
       LaunchTimer lt(c, s, 4);
       hipLaunchKernelGGL(index_units_kernel, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
@@ -445,6 +451,14 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     {
       LaunchTimer lt(c, s, 0);
       hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+    }
+    if (d_stats) {
+      unsigned long long h[8];
+      HIP_TRY(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      fprintf(stderr, "STATS pool: rounds %llu spins %llu batches %llu copies %llu | front: trips %llu steps %llu bitmap-steps %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+      (void)hipFree(d_stats);
     }
   }
   if (stream_pass) {
