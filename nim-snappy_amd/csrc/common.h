@@ -19,6 +19,9 @@ constexpr uint32_t kMaskDelta = 0xa282ead8u;        // crc32c.c:49
 constexpr uint32_t kOk = 0, kBufferTooSmall = 1, kInvalidInput = 2, kCrcMismatch = 3;
 // Internal: the unit does not fit the 64 KiB LDS window, run the whole-stream kernel.
 constexpr uint32_t kNeedsStreamKernel = 0x80000000u;
+// Internal: the indexed decoder declined the unit (a limit of its fast path), run the one-pass
+// block kernel on it.
+constexpr uint32_t kNeedsOnePass = 0x80000001u;
 
 enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
 
@@ -40,15 +43,27 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// Exclusive prefix sum over the 64 lanes; *total receives the wave sum.
+// Exclusive prefix sum over the 64 lanes; *total receives the wave sum.  DPP only (row shifts
+// inside each row of 16, then row broadcasts), no trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov0(uint32_t v) {  // lanes without a source read 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
   uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if (lane >= (uint32_t)d) x += y;
+  x += dpp_mov0<0x111>(x);  // row_shr:1
+  x += dpp_mov0<0x112>(x);  // row_shr:2
+  x += dpp_mov0<0x114>(x);  // row_shr:4
+  x += dpp_mov0<0x118>(x);  // row_shr:8
+  {
+    const uint32_t t = dpp_mov0<0x142>(x);  // row_bcast:15 -> lane 15 of a row into the next row
+    if ((lane & 31) >= 16) x += t;
   }
-  *total = __shfl(x, 63, 64);
+  {
+    const uint32_t t = dpp_mov0<0x143>(x);  // row_bcast:31 -> lane 31 into lanes 32..63
+    if (lane >= 32) x += t;
+  }
+  *total = readlane(x, 63);
   return x - v;
 }
 

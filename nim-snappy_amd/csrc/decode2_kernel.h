@@ -36,9 +36,14 @@
 
 namespace snappy_hip {
 
-constexpr uint32_t kD2Threads = 256;
+constexpr uint32_t kD2Threads = 320;  // waves 0,1: front end; waves 2-4: resolver pool
+// (a workgroup's waves are dealt round-robin to the 4 SIMDs: waves 0 and 4 share one, so the
+// two front-end waves must not be 0 and 4)
 constexpr uint32_t kD2Ring = 4096;
-constexpr uint32_t kListCap = 1024;             // a 2 KiB chunk holds at most 1024 copy elements
+constexpr uint32_t kListCap = 896;  // copy elements per 2 KiB chunk on the fast path (1024 is the
+                                   // format's maximum; such a unit goes to the one-pass kernel)
+constexpr uint32_t kPendBits = 16384;  // window of the pending-byte bitmap (output positions)
+constexpr uint32_t kPendWords = kPendBits / 32;
 constexpr uint32_t kOutSink = kMaxBlockLen + 16; // 64 scratch dwords behind the output window,
 constexpr uint32_t kOutAlloc = kMaxBlockLen + 16 + 256 + 16;  // one per lane (no bank conflicts)
 
@@ -89,9 +94,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   __shared__ uint32_t s_xdone[2];  // far-copy waves finished with list k
   __shared__ uint32_t s_near[2][2];  // near copies left in each half of list k after compaction
   __shared__ uint32_t s_mode[2];     // list k is resolved through the pending-byte bitmap
+  __shared__ uint32_t s_sbase[kMaxFastIn / kChunk + 2];  // output position where step k starts
   // One bit per output byte (position mod 8192): set while a copy that produces the byte is
   // still unresolved.  A copy may run as soon as no bit of its source range is set.
-  __shared__ unsigned long long s_pend[128];
+  __shared__ unsigned long long s_pend[kPendWords / 2];
   __shared__ uint32_t s_err;
 
   const uint32_t tid = threadIdx.x;
@@ -118,8 +124,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
   const uint8_t* g0 = in0 - shift;
   const uint32_t q_end = (uint32_t)(((uint64_t)shift + n + 15) & ~15ull);
-  const uint32_t n_chunks = (n + kChunk - 1) / kChunk;
-  const uint32_t n_regions = (n + kRegion - 1) / kRegion;
+  const uint32_t n_chunks = (n + kChunk - 1) / kChunk;   // 2 KiB steps
+  const uint32_t n_regions = (n + kSub - 1) / kSub;       // 16-byte index entries
+  const bool fe = wave <= 1;                             // front-end waves
+  const uint32_t half = wave == 1 ? 1 : 0;               // which 1 KiB of the step is mine
 
   if (tid == 0) {
     s_err = 0;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_mode[0] = 0;
     s_mode[1] = 0;
   }
-  for (uint32_t i = tid; i < 128; i += kD2Threads) s_pend[i] = 0;
+  for (uint32_t i = tid; i < kPendWords / 2; i += kD2Threads) s_pend[i] = 0;
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
   // [2048 s, 2048 s + 4096)
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   auto ring_al = [&](uint32_t q) -> uint32_t {  // aligned dword that holds stream byte q - shift
     return *reinterpret_cast<const uint32_t*>(s_ring + (q & (kD2Ring - 1) & ~3u));
   };
-  // pending-byte bitmap as 256 dwords; a run of len bits at pos touches up to three of them
+  // pending-byte bitmap as dwords; a run of len bits at pos touches up to three of them
   uint32_t* const pw = reinterpret_cast<uint32_t*>(s_pend);
   auto bits_make = [&](uint32_t pos, uint32_t len, uint32_t* d0, uint32_t* d1, uint32_t* d2) {
     const uint32_t sh = pos & 31;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     *d2 = sh ? (uint32_t)(m >> (64 - sh)) : 0;
   };
 
-  if (wave == 0) {  // prologue: first 4 KiB of the stream
+  if (wave == 1) {  // prologue: first 4 KiB of the stream
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t q = (lane + 64 * i) * 16;
@@ -215,58 +223,85 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   }
   __syncthreads();
 
-  // index entries of the current and the next chunk (front-end wave; loaded two steps ahead)
-  uint32_t ie_cur = kIdxNone, ie_nxt = kIdxNone;
-  if (wave == 0) {
-    ie_cur = lane < n_regions ? idx[lane] : kIdxNone | (total << 11);
-    ie_nxt = 64 + lane < n_regions ? idx[64 + lane] : kIdxNone | (total << 11);
-  }
-  uint32_t cprev = 0;  // output position where the previous chunk starts
+  // Index entries of the NEXT step (mine and the other front-end wave's) are fetched at the start
+  // of a step and consumed at the start of the next one, before anything younger is issued, so
+  // the wait for them never also waits for fresh loads.  Entries past the end read as "none".
+  const uint32_t none_end = kIdxNone | (total << 11);
+  auto idx_at = [&](uint32_t r) -> uint32_t { return r < n_regions ? idx[r] : none_end; };
+  // (every wave executes these loads -- straight-line code keeps the compiler from copying the
+  // loaded registers, and thereby waiting for them, at the end of the front-end branch)
+  uint32_t ie_pref = idx_at(half * 64 + lane);
+  uint32_t io_pref = idx_at((1 - half) * 64 + lane);
+  for (uint32_t k = tid; k <= n_chunks && k < kMaxFastIn / kChunk + 2; k += kD2Threads)
+    s_sbase[k] = k < n_chunks ? idx_at(k * 128) >> 11 : total;
+  __syncthreads();
+  uint32_t cprev = 0;  // output position where the previous step starts
+  uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
 
+  unsigned long long tm_pre = 0, tm_walk = 0, tm_post = 0, tm_bar = 0;
   for (uint32_t s = 0; s <= n_chunks; s++) {
-    if (wave == 0 && s < n_chunks) {
+    if (s_err) break;  // set before the last barrier: every wave sees it here
+    const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tm1 = tm0, tm2 = tm0;
+    // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
+    // everything fetched during the previous step is consumed here, BEFORE new loads are issued
+    // (the empty asm pins the wait to this point)
+    asm volatile("" ::"v"(ie_pref), "v"(io_pref), "v"(pre[0].x), "v"(pre[0].w), "v"(pre[1].x),
+                 "v"(pre[1].w));
+    const uint32_t ie = ie_pref, io_cur = io_pref;  // index entries of this step
+    if (wave == 1 && s < n_chunks) {
+      // the ring slots of the previous step are free now: land the 2 KiB fetched meanwhile
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+        if (pq[i] < q_end) ring_store(pq[i], pre[i]);
+    }
+    // next step's index entries and the 2 KiB of stream after the ring's contents
+    ie_pref = idx_at((s + 1) * 128 + half * 64 + lane);
+    io_pref = idx_at((s + 1) * 128 + (1 - half) * 64 + lane);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      pq[i] = s * kChunk + kD2Ring + (lane + 64 * i) * 16;
+      const uint32_t qc = pq[i] < q_end ? pq[i] : 0;  // clamped: always a valid address
+      pre[i] = *reinterpret_cast<const uint4*>(g0 + qc);
+    }
+
+    if (fe && s < n_chunks) {
       // =================================== front end ===========================================
       const uint32_t buf = s & 1;
-      const uint32_t c0 = s * kChunk;
-      // loads for the step after next, landed at the end of this step
-      uint4 pre[2];
-      uint32_t pq[2];
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        pq[i] = c0 + kD2Ring + (lane + 64 * i) * 16;
-        pre[i] = make_uint4(0, 0, 0, 0);
-        if (pq[i] < q_end) pre[i] = *reinterpret_cast<const uint4*>(g0 + pq[i]);
-      }
-      const uint32_t r2 = (s + 2) * 64 + lane;
-      const uint32_t ie_far = r2 < n_regions ? idx[r2] : kIdxNone | (total << 11);  // for step s+2
-      const uint32_t ie = ie_cur;
+      const uint32_t c0 = s * kChunk + half * (kChunk / 2);
       const uint32_t e_off = ie & 63;
       const bool had = e_off != kIdxNone;
       const uint32_t ncopy = had ? (ie >> 6) & 31 : 0;
+      const uint32_t ocopy = (io_cur & 63) != kIdxNone ? (io_cur >> 6) & 31 : 0;
       uint32_t dst = ie >> 11;
-      uint32_t ctot;
+      uint32_t ctot, otot;
       uint32_t slot = wave_excl_scan(ncopy, lane, &ctot);
-      if (lane == 0) {
-        s_cnt[buf] = ctot;
+      (void)wave_excl_scan(ocopy, lane, &otot);
+      if (half) slot += otot;  // the first half's copies come first in the list
+      ctot += otot;            // copies of the whole step
+      if (wave == 0 && lane == 0) {
+        s_cnt[buf] = ctot <= kListCap ? ctot : 0;
         s_xdone[buf] = 0;
+        if (ctot > kListCap) s_err = 2;  // too dense for the fast path: one-pass kernel
       }
-      const uint32_t cbase = readlane(dst, 0);           // output position where this chunk starts
-      const uint32_t cnext = readlane(ie_nxt >> 11, 0);  // ... and where the next one starts
-      // bitmap mode needs this chunk and the previous one to fit the 8192-position window
-      const bool bm = cnext - cprev <= 8192 - 256;
-      if (lane == 0) s_mode[buf] = bm ? 1 : 0;
+      if (ctot > kListCap) slot = kListCap;  // all appends of this step go to the sink slots
+      // output position where this step starts / the next one starts
+      const uint32_t cbase = s_sbase[s], cnext = s_sbase[s + 1];
+      // bitmap mode needs this step and the previous one to fit the window
+      const bool bm = cnext - cprev <= kPendBits - 256 && ctot <= kListCap;
+      if (wave == 0 && lane == 0) s_mode[buf] = bm ? 1 : 0;
       cprev = cbase;
-      ie_cur = ie_nxt;
-      ie_nxt = ie_far;
 
-      const uint32_t rs = c0 + lane * kRegion;
-      const uint32_t r_end = rs + kRegion < n ? rs + kRegion : n;
+      const uint32_t rs = c0 + lane * kSub;
+      const uint32_t r_end = rs + kSub < n ? rs + kSub : n;
       uint32_t pos = rs + e_off;
-      bool live = had && pos < n && !(prm.dbg & 4);
+      bool live = had && pos < n && !(prm.dbg & 4) && !((prm.dbg & 16) && half == 1) && !((prm.dbg & 32) && half == 0);
       bool big = false;  // a literal longer than 64 bytes ends my region: done below
       uint32_t big_dst = 0, big_len = 0, big_src = 0;
       bool bad = false;
       uint32_t st_trips = 0;
+      tm1 = __builtin_amdgcn_s_memtime();
       while (ballot(live)) {
         st_trips++;
         const uint32_t q = pos + shift;
@@ -281,7 +316,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         // ---- copy: append to the list (sink slot when this lane has no copy) ------------------
         const bool bad_off = cpy && (off == 0 || off > dst);  // decoder.nim:112
         bad = bad || bad_off;
-        const uint32_t sl = cpy ? slot : kListCap + lane;
+        const uint32_t sl = (cpy && slot < kListCap) ? slot : kListCap + lane;
         s_cp[buf][sl] = bad_off ? (dst | (1u << 16)) : (dst | (off << 16));
         // bit 7: source ends below this chunk's output = independent of every unresolved copy
         const uint32_t far = (dst - off + L <= cbase) ? 0x80u : 0u;
@@ -290,10 +325,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (bm) {  // mark the bytes this copy will produce as pending
           uint32_t d0, d1, d2;
           bits_make(dst, (cpy && !bad_off) ? L : 0, &d0, &d1, &d2);
-          const uint32_t w = (dst & 8191) >> 5;
+          const uint32_t w = (dst & (kPendBits - 1)) >> 5;
           atomicOr(pw + w, d0);
-          atomicOr(pw + ((w + 1) & 255), d1);
-          if (ballot(d2 != 0)) atomicOr(pw + ((w + 2) & 255), d2);
+          atomicOr(pw + ((w + 1) & (kPendWords - 1)), d1);
+          if (ballot(d2 != 0)) atomicOr(pw + ((w + 2) & (kPendWords - 1)), d2);
         }
         // ---- literal: payload of up to 16 bytes here, up to 64 in the rare loop below -----------
         const uint32_t qs = q + hdr;
@@ -309,6 +344,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         pos += live ? size : 0;
         live = live && pos < r_end;
       }
+      tm2 = __builtin_amdgcn_s_memtime();
       // long literals: whole wave, straight from HBM (at most one per region)
       uint64_t bigs = ballot(big);
       while (bigs) {
@@ -337,16 +373,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (body + lane < eL) s_out[ed + body + lane] = in0[es + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
-      if (prm.stats && lane == 0) {
+      if (prm.stats && lane == 0 && wave == 0) {
         atomicAdd(&prm.stats[4], (unsigned long long)st_trips);
         atomicAdd(&prm.stats[5], 1ull);
         atomicAdd(&prm.stats[6], (unsigned long long)(bm ? 1 : 0));
       }
-      // the ring slots of this chunk are free now: land the prefetched 2 KiB
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-        if (pq[i] < q_end) ring_store(pq[i], pre[i]);
-    } else if (wave >= 1 && s >= 1 && s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
+    } else if (wave >= 2 && s >= 1 && s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
       // =================================== resolver pool ==========================================
       // Three waves share the previous step's list (batches round-robin).  Dependencies are
       // exact: a copy runs when no byte of its source is still pending, whichever wave owns the
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       // owner is always working on its batch, so the pool cannot dead-lock.
       const uint32_t buf = (s - 1) & 1;
       const uint32_t count = s_cnt[buf];
-      for (uint32_t b0 = (wave - 1) * 64; b0 < count; b0 += 192) {
+      for (uint32_t b0 = (wave - 2) * 64; b0 < count; b0 += 192) {
         const uint32_t i = b0 + lane;
         const uint32_t lf = i < count ? s_cl[buf][i] : 0;
         const uint32_t e = s_cp[buf][i];
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         bits_make(dst, len, &m0, &m1, &m2);             // the bytes I produce
         const uint32_t slen = ovl ? off : len;
         bits_make(src, slen, &q0, &q1, &q2);            // the bytes I need
-        const uint32_t bw = (dst & 8191) >> 5, sw = (src & 8191) >> 5;
+        const uint32_t bw = (dst & (kPendBits - 1)) >> 5, sw = (src & (kPendBits - 1)) >> 5;
         const bool wide = ballot(m2 != 0 || q2 != 0) != 0;
         uint64_t pend = ballot(act);
         uint32_t st_rounds = 0, st_spins = 0;
@@ -376,13 +408,17 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           st_rounds++;
           uint32_t busy =
               (__hip_atomic_load(pw + sw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q0) |
-              (__hip_atomic_load(pw + ((sw + 1) & 255), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q1);
+              (__hip_atomic_load(pw + ((sw + 1) & (kPendWords - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q1);
           if (wide)
-            busy |= __hip_atomic_load(pw + ((sw + 2) & 255), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q2;
+            busy |= __hip_atomic_load(pw + ((sw + 2) & (kPendWords - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q2;
           const bool rdy = ((pend >> lane) & 1) && (far || busy == 0);
           const uint64_t rm = ballot(rdy);
           if (rm == 0) {  // everything left waits for another wave
             st_spins++;
+            if (st_spins > 400000) {  // cannot happen on a consistent index; never hang the GPU
+              if (lane == 0) atomicOr(&s_err, 4u);
+              break;
+            }
             __builtin_amdgcn_s_sleep(1);
             continue;
           }
@@ -398,10 +434,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           }
           wave_fence();
           __hip_atomic_fetch_and(pw + bw, rdy ? ~m0 : ~0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_and(pw + ((bw + 1) & 255), rdy ? ~m1 : ~0u, __ATOMIC_RELEASE,
+          __hip_atomic_fetch_and(pw + ((bw + 1) & (kPendWords - 1)), rdy ? ~m1 : ~0u, __ATOMIC_RELEASE,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
           if (wide)
-            __hip_atomic_fetch_and(pw + ((bw + 2) & 255), rdy ? ~m2 : ~0u, __ATOMIC_RELEASE,
+            __hip_atomic_fetch_and(pw + ((bw + 2) & (kPendWords - 1)), rdy ? ~m2 : ~0u, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
           pend &= ~rm;
         }
@@ -412,14 +448,14 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           atomicAdd(&prm.stats[3], (unsigned long long)__builtin_popcountll(ballot(act)));
         }
       }
-    } else if (wave >= 2 && s >= 1 && !(prm.dbg & 2)) {
+    } else if (wave >= 3 && s >= 1 && !(prm.dbg & 2)) {
       // =================================== far copies ============================================
       const uint32_t buf = (s - 1) & 1;
       const uint32_t count = s_cnt[buf];
       // each of the two waves owns one contiguous half of the list: it executes the far copies
       // and compacts the remaining (near) ones in place, in order, at the front of its half
       const uint32_t half = ((count + 127) / 128) * 64;
-      const uint32_t seg0 = (wave - 2) * half;
+      const uint32_t seg0 = (wave - 3) * half;
       const uint32_t seg1 = seg0 + half < count ? seg0 + half : count;
       uint32_t wpos = seg0;
       for (uint32_t b0 = seg0; b0 < seg1; b0 += 64) {
@@ -440,12 +476,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         s_cl[buf][to] = (uint8_t)len;
         wpos += (uint32_t)__builtin_popcountll(nm);
       }
-      if (lane == 0) s_near[buf][wave - 2] = wpos - seg0;
+      if (lane == 0) s_near[buf][wave - 3] = wpos - seg0;
       wave_fence();
       if (lane == 0) atomicAdd(&s_xdone[buf], 1u);
-    } else if (wave == 1 && s >= 1 && !(prm.dbg & 2)) {
+    } else if (wave == 2 && s >= 1 && !(prm.dbg & 2)) {
       // =================================== resolver ==============================================
-      while (__hip_atomic_load(&s_xdone[(s - 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2)
+      for (uint32_t spin = 0; __hip_atomic_load(&s_xdone[(s - 1) & 1], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP) < 2 && spin < 400000; spin++)
         __builtin_amdgcn_s_sleep(2);
       wave_fence();
       const uint32_t buf = (s - 1) & 1;
@@ -524,12 +561,28 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         }
       }
     }
-    __syncthreads();
+    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+    // Workgroup barrier for LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait
+    // for the global prefetches that are meant to stay in flight across the barrier.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
+    if (wave == 0) {
+      tm_pre += tm1 - tm0;
+      tm_walk += tm2 - tm1;
+      tm_post += tm3 - tm2;
+      tm_bar += tm4 - tm3;
+    }
+  }
+  if (prm.stats && tid == 0) {
+    atomicAdd(&prm.stats[7], tm_pre);
+    atomicAdd(&prm.stats[8], tm_walk);
+    atomicAdd(&prm.stats[9], tm_post);
+    atomicAdd(&prm.stats[10], tm_bar);
   }
 
   // ---- flush ------------------------------------------------------------------------------------
   if (s_err) {
-    if (tid == 0) prm.status[u] = kInvalidInput;
+    if (tid == 0) prm.status[u] = (s_err & 1) ? kInvalidInput : kNeedsOnePass;
     return;
   }
   if (prm.dbg & 8) return;
@@ -554,12 +607,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
 // Region count per unit for the index (bounded: the index pass stops once a unit has produced
 // more than 64 KiB, which takes at most 6 stream bytes per output byte).
-constexpr uint32_t kMaxRegionsPerUnit = (6 * kMaxBlockLen + 2 * kChunk) / kRegion + 4;
+constexpr uint32_t kMaxRegionsPerUnit = kMaxFastIn / kSub + 8;  // index entries (16 bytes each)
 
 __global__ void region_counts_kernel(const uint32_t* in_len, uint64_t n_units, uint32_t* counts) {
   const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
   if (i >= n_units) return;
-  const uint64_t c = ((uint64_t)in_len[i] + kRegion - 1) / kRegion + 1;
+  const uint64_t c = ((uint64_t)in_len[i] + kSub - 1) / kSub + 2;
   counts[i] = c < kMaxRegionsPerUnit ? (uint32_t)c : kMaxRegionsPerUnit;
 }
 

@@ -40,6 +40,7 @@ struct DecodeParams {
   uint64_t n_units;
   int unit;
   int dbg;  // timing experiments only: 1 skip literals, 2 skip copies, 4 skip flush
+  uint32_t only_status;  // block kernel: if non-zero, handle only units in this state
 };
 
 constexpr int kUnitStored = 3;  // internal: verbatim bytes (uncompressed framed chunk)
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
   if (OUT_GLOBAL) {
     // only units the block kernel handed over
     if (prm.status[unit_idx] != kNeedsStreamKernel) return;
+  } else if (prm.only_status) {
+    if (prm.status[unit_idx] != prm.only_status) return;
   }
 
   const uint8_t* in0 = prm.in + prm.in_off[unit_idx];

@@ -20,9 +20,13 @@
 //   3. A wave prefix sum of the per-region output byte counts gives every region its output
 //      position.
 //
-// Index entry per 32-byte region (u32):  [0:6) offset of the first element in the region
-// (32 = none)  [6:11) copy elements that start in the region  [11:28) output position of
-// that first element.
+//   4. Each lane then walks its own region once more (one size-table read per element) to split
+//      its entry at the 16-byte boundary, so the decode kernel can give every 16 bytes of
+//      stream its own lane.
+//
+// Index entry per 16 bytes of stream (u32):  [0:6) offset of the first element that starts in
+// them (32 = none)  [6:11) copy elements that start in them  [11:28) output position of that
+// first element.
 //
 // All input-side checks of decodeAllTags (truncated elements, the 61-byte rule of
 // decoder.nim:54-57, 4-byte length wrap :67-68, length bounds :77-79 / :127-128 through the
@@ -41,6 +45,11 @@ constexpr uint32_t kExitEnd = 0, kExitErr = 1;      // exit field: chain ended /
 constexpr uint32_t kExitFar = 992;                  // exit field >= 992: far exit, k = value-992
 constexpr uint32_t kOutSat = 0x1ffff;               // saturated output count (> 65536 = invalid)
 constexpr uint32_t kIdxNone = 32;
+constexpr uint32_t kSub = 16;                       // stream bytes per index entry (half a region)
+constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's row in the size table
+// Longest tag stream the indexed path takes (a valid 64 KiB block needs at most 76 490 bytes,
+// snappy/codec.nim:217); longer units go to the one-pass kernel.
+constexpr uint32_t kMaxFastIn = 98304;
 
 __device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t ncopy, uint32_t outsum) {
   return exit_rel | (ncopy << 10) | (outsum << 15);
@@ -48,6 +57,10 @@ __device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t ncopy, ui
 __device__ __forceinline__ uint32_t t_exit(uint32_t t) { return t & 1023; }
 __device__ __forceinline__ uint32_t t_ncopy(uint32_t t) { return (t >> 10) & 31; }
 __device__ __forceinline__ uint32_t t_out(uint32_t t) { return t >> 15; }
+// value of lane-1 (0 for lane 0) through DPP, no LDS round trip
+__device__ __forceinline__ uint32_t lane_prev_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
 
 struct IndexParams {
   const uint8_t* in;
@@ -149,17 +162,22 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   // what an over-long output means: a bigger unit goes to the whole-stream kernel
   const uint32_t too_long = limit > win_limit ? kNeedsStreamKernel : kInvalidInput;
 
-  const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
-  const uint8_t* g0 = in0 - shift;                          // 16-byte aligned
-  const uint64_t g_end = ((uint64_t)shift + n + 15) & ~15ull;  // aligned end of the unit
+  if (n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // positions below fit 32 bits
 
-  uint64_t entry_abs = 0;  // stream position of the next real element (uniform)
-  uint64_t op = 0;         // output bytes before it (uniform)
+  __shared__ uint8_t s_sz[64 * kSizeStride];  // stream size of the element at each position
+
+  const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
+  const uint8_t* g0 = in0 - shift;                // 16-byte aligned
+  const uint32_t g_end = (shift + n + 15) & ~15u;  // aligned end of the unit
+
+  uint32_t entry_abs = 0;  // stream position of the next real element (uniform)
+  uint32_t op = 0;         // output bytes before it (uniform)
   bool ended = false;
   const uint32_t row = lane * kRowStride;
+  const uint32_t row8 = lane * kSizeStride;
 
-  for (uint64_t c0 = 0; c0 < n && !ended; c0 += kChunk) {
-    const uint64_t rs = c0 + (uint64_t)lane * kRegion;  // my region's first stream position
+  for (uint32_t c0 = 0; c0 < n && !ended; c0 += kChunk) {
+    const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position
     uint32_t entry_off = kIdxNone, out_here = 0, ncopy_here = 0;
 
     if (entry_abs < c0 + kChunk) {  // otherwise a long literal covers the whole chunk
@@ -167,8 +185,8 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       uint32_t w[10];
       {
         uint32_t a[16];
-        const uint64_t q = rs + shift;
-        const uint64_t qa = q & ~15ull;
+        const uint32_t q = rs + shift;
+        const uint32_t qa = q & ~15u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           uint4 v = make_uint4(0, 0, 0, 0);
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
           a[4 * i + 2] = v.z;
           a[4 * i + 3] = v.w;
         }
-        const uint32_t sh = (uint32_t)(q & 15);
+        const uint32_t sh = q & 15;
         const uint32_t dsh = sh >> 2, bsh = (sh & 3) * 8;
         // dword-granular part of the shift with selects, byte part with a funnel shift
         uint32_t b[11];
@@ -193,8 +211,9 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       // ---- right-to-left pass over my 32 positions --------------------------------------------
 #pragma unroll
       for (int k = kRegion - 1; k >= 0; k--) {
-        const uint64_t p = rs + k;
+        const uint32_t p = rs + k;
         uint32_t t;
+        uint32_t szb = 255;
         if (p >= n) {
           t = t_pack(kExitEnd, 0, 0);
         } else {
@@ -204,8 +223,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
           const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
           const uint32_t tag = d0 & 0xff;
           const uint32_t b14 = (d0 >> 8) | (d1 << 24);
-          const uint64_t rem64 = (uint64_t)n - p - 1;
-          const uint32_t rem = rem64 > 0xffffffffull ? 0xffffffffu : (uint32_t)rem64;
+          const uint32_t rem = n - p - 1;
           bool is_copy;
           uint32_t L, size, hdr, off;
           const bool ok = decode_element(tag, b14, rem, &is_copy, &L, &size, &hdr, &off);
@@ -213,11 +231,12 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
           if (!ok) {
             t = t_pack(kExitErr, 0, 0);
           } else {
-            const uint64_t nx = (uint64_t)k + size;
+            szb = size < 255 ? size : 255;
+            const uint32_t nx = (uint32_t)k + size;  // ok => size <= rem + 1: no wrap
             if (nx >= kRegion) {
-              t = t_pack(nx < kExitFar ? (uint32_t)nx : kExitFar + (uint32_t)k, is_copy ? 1 : 0, Ls);
+              t = t_pack(nx < kExitFar ? nx : kExitFar + (uint32_t)k, is_copy ? 1 : 0, Ls);
             } else {
-              const uint32_t tn = s_tab[row + (uint32_t)nx];
+              const uint32_t tn = s_tab[row + nx];
               if (t_exit(tn) == kExitErr) {
                 t = tn;
               } else {
@@ -229,26 +248,27 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
           }
         }
         s_tab[row + k] = t;
+        s_sz[row8 + k] = (uint8_t)szb;
       }
       wave_fence();
 
       // ---- chain across the regions: fixed point ------------------------------------------------
       // in_abs = stream position at which the element chain arrives at my region (>= rs)
-      uint64_t in_abs = lane == 0 ? entry_abs : rs;
-      uint64_t out_abs;
+      uint32_t in_abs = lane == 0 ? entry_abs : rs;
+      uint32_t out_abs;
       uint32_t tv = 0;
       bool has;
       for (;;) {
         has = in_abs < rs + kRegion;
         out_abs = in_abs;
         if (has) {
-          tv = s_tab[row + (uint32_t)(in_abs - rs)];
+          tv = s_tab[row + (in_abs - rs)];
           const uint32_t ex = t_exit(tv);
           if (ex == kExitEnd || ex == kExitErr) {
-            out_abs = ~0ull;  // nothing follows
+            out_abs = 0xffffffffu;  // nothing follows
           } else if (ex >= kExitFar) {
             // far exit: a long literal at offset ex-992; re-read its header from HBM (rare)
-            const uint64_t fp = rs + (ex - kExitFar);
+            const uint32_t fp = rs + (ex - kExitFar);
             const uint32_t ftag = in0[fp];
             uint32_t fb = 0;
             for (uint32_t i = 0; i < 4 && fp + 1 + i < n; i++) fb |= (uint32_t)in0[fp + 1 + i] << (8 * i);
@@ -260,9 +280,8 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
             out_abs = rs + ex;
           }
         }
-        uint32_t lo = __shfl_up((uint32_t)out_abs, 1, 64);
-        uint32_t hi = __shfl_up((uint32_t)(out_abs >> 32), 1, 64);
-        const uint64_t nin = lane == 0 ? entry_abs : (((uint64_t)hi << 32) | lo);
+        const uint32_t prev = lane_prev_u32(out_abs);
+        const uint32_t nin = lane == 0 ? entry_abs : prev;
         const bool changed = nin != in_abs;
         in_abs = nin;
         if (!ballot(changed)) break;
@@ -272,23 +291,44 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       const bool bad = has && t_exit(tv) == kExitErr;
       if (ballot(bad)) return finish(kInvalidInput, 0);
       if (has && in_abs < n) {  // in_abs == n is the end of the stream, not an element
-        entry_off = (uint32_t)(in_abs - rs);
+        entry_off = in_abs - rs;
         out_here = t_out(tv);
         ncopy_here = t_ncopy(tv);
       }
       ended = ballot(has && t_exit(tv) == kExitEnd) != 0;
-      const uint32_t last_lo = readlane((uint32_t)out_abs, 63);
-      const uint32_t last_hi = readlane((uint32_t)(out_abs >> 32), 63);
-      entry_abs = ((uint64_t)last_hi << 32) | last_lo;
+      entry_abs = readlane(out_abs, 63);
     }
 
     // output positions: saturating counts keep the sum below 2^32 (64 * 0x1ffff)
     uint32_t tot;
     const uint32_t before = wave_excl_scan(out_here, lane, &tot);
     if (op + tot > win_limit) return finish(too_long, 0);
+
+    // ---- split my entry at the 16-byte boundary -------------------------------------------------
+    const uint32_t pos0 = op + before;
+    uint32_t e0 = kIdxNone, e1 = kIdxNone, nc0 = 0, nc1 = 0, pos1 = pos0 + out_here;
+    {
+      uint32_t pw = entry_off;  // walk to the first element at or after byte 16 (none = 32)
+      while (ballot(pw < kSub)) {
+        if (pw < kSub) pw += s_sz[row8 + pw];
+      }
+      uint32_t out_second = 0, nc_second = 0;
+      if (entry_off != kIdxNone && pw < kRegion && rs + pw < n) {  // an element in the second half
+        const uint32_t t2 = s_tab[row + pw];
+        out_second = t_out(t2);
+        nc_second = t_ncopy(t2);
+        e1 = pw - kSub;
+        nc1 = nc_second;
+        pos1 = pos0 + (out_here - out_second);
+      }
+      if (entry_off < kSub) {
+        e0 = entry_off;
+        nc0 = ncopy_here - nc_second;
+      }
+    }
     if (rs < n) {
-      const uint32_t pos = (uint32_t)op + before;
-      idx[rs / kRegion] = entry_off | (ncopy_here << 6) | (pos << 11);
+      idx[2 * (rs / kRegion)] = e0 | (nc0 << 6) | (pos0 << 11);
+      idx[2 * (rs / kRegion) + 1] = e1 | (nc1 << 6) | (pos1 << 11);
     }
     op += tot;
   }
@@ -296,9 +336,8 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
-  finish(kOk, (uint32_t)op);
+  finish(kOk, op);
 }
-
 
 // DEBUG: serial check of the index of one unit against a plain walk (one thread per unit).
 // report[u*4..]: region of the first mismatch (or ~0), expected entry, got entry.
@@ -318,13 +357,13 @@ __global__ void verify_index_kernel(IndexParams prm, uint32_t* report) {
   }
   const uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride);
   uint32_t pos = 0, dst = 0;
-  const uint32_t nreg = (n + kRegion - 1) / kRegion;
+  const uint32_t nreg = (n + kSub - 1) / kSub;
   for (uint32_t r = 0; r < nreg; r++) {
-    const uint32_t rs = r * kRegion;
+    const uint32_t rs = r * kSub;
     uint32_t want = kIdxNone | (dst << 11);
-    if (pos < rs + kRegion && pos < n) {
+    if (pos < rs + kSub && pos < n) {
       uint32_t e_off = pos - rs, d0 = dst, nc = 0;
-      while (pos < rs + kRegion && pos < n) {
+      while (pos < rs + kSub && pos < n) {
         uint32_t b = 0;
         for (uint32_t i = 0; i < 4 && pos + 1 + i < n; i++) b |= (uint32_t)in0[pos + 1 + i] << (8 * i);
         bool c;

@@ -423,8 +423,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
     unsigned long long* d_stats = nullptr;
     if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
-      HIP_TRY(hipMalloc((void**)&d_stats, 64));
-      HIP_TRY(hipMemsetAsync(d_stats, 0, 64, s));
+      HIP_TRY(hipMalloc((void**)&d_stats, 128));
+      HIP_TRY(hipMemsetAsync(d_stats, 0, 128, s));
       dp.stats = d_stats;
     }
     {
@@ -453,13 +453,21 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
     }
     if (d_stats) {
-      unsigned long long h[8];
-      HIP_TRY(hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, s));
+      unsigned long long h[16];
+      HIP_TRY(hipMemcpyAsync(h, d_stats, 128, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       fprintf(stderr, "STATS pool: rounds %llu spins %llu batches %llu copies %llu | front: trips %llu steps %llu bitmap-steps %llu\n",
               h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+      fprintf(stderr, "STATS wave0 ticks per step: pre %.0f walk %.0f post %.0f barrier %.0f\n", (double)h[7] / h[5],
+              (double)h[8] / h[5], (double)h[9] / h[5], (double)h[10] / h[5]);
       (void)hipFree(d_stats);
     }
+  }
+  if (!v1 && !getenv("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined
+    LaunchTimer lt(c, s, 5);
+    p.only_status = kNeedsOnePass;
+    hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+    p.only_status = 0;
   }
   if (stream_pass) {
     LaunchTimer lt(c, s, 5);
@@ -642,8 +650,13 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   HIP_TRY(hipMemcpyAsync(d_oc, oc.data(), nu * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_kd, kd.data(), nu, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_ol, 0, nu * 4, s));
-  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nu, 0,
-                     (const uint8_t*)d_kd, (uint8_t*)d_out, (const uint64_t*)d_oo,
+  // uniform batches (no stored chunks among them) take the indexed decoder
+  bool uniform = true;
+  for (size_t i = 1; i < nu; i++) uniform = uniform && kd[i] == kd[0];
+  uniform = uniform && kd[0] != (uint8_t)kUnitStored;
+  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nu,
+                     uniform ? (int)kd[0] : 0, uniform ? nullptr : (const uint8_t*)d_kd,
+                     (uint8_t*)d_out, (const uint64_t*)d_oo,
                      (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
     return st;
   if (want_crc) {

@@ -189,6 +189,28 @@ def test_large_raw_stream_takes_stream_kernel(hip, orc):
     assert hip.decode(bytes(stream)) == want
 
 
+def test_dense_copy_stream_takes_one_pass_kernel(hip, orc):
+    """a chunk with more copy elements than the indexed decoder's list holds (only a foreign
+    encoder produces this) is handed to the one-pass kernel; same result as the oracle"""
+    n_copies = 3000
+    out_len = 4 + 4 * n_copies
+    stream = bytearray()
+    v = out_len
+    while v >= 0x80:
+        stream.append((v & 0x7f) | 0x80)
+        v >>= 7
+    stream.append(v)
+    stream += bytes([3 << 2]) + b"abcd"
+    stream += bytes([0x01, 0x04]) * n_copies  # copy1: len 4, offset 4
+    want = orc.decode(bytes(stream))
+    assert want == b"abcd" * (n_copies + 1)
+    assert hip.decode(bytes(stream)) == want
+    # short copies (len 1..3, copy2 only) and a self-overlapping run, also foreign
+    s2 = bytearray([20, 3 << 2]) + b"wxyz" + bytes([(0 << 2) | 2, 4, 0, (1 << 2) | 2, 2, 0,
+                                                      (2 << 2) | 2, 1, 0, (9 << 2) | 2, 3, 0])
+    assert hip.decode(bytes(s2)) == orc.decode(bytes(s2)) != b""
+
+
 def test_full_size_round_trip_properties(hip, torch_mod):
     """BASELINE size (65 536 x 64 KiB = 4 GiB; SNAPPY_HIP_TEST_BLOCKS overrides): compress ->
     pack -> decompress on the device restores every byte, all statuses ok, packed offsets
