@@ -85,8 +85,14 @@ __device__ __forceinline__ void decode_fast(uint32_t tag, uint32_t b14, bool* is
   *size = t == 0 ? 1 + lenlen + Llit : (t == 1 ? 2 : (t == 2 ? 3 : 5));
 }
 
+// The 64 KiB output window is DYNAMIC shared memory (launch with kOutAlloc bytes): with the whole
+// footprint declared statically the compiler derives "at most 3 waves per SIMD" from it and pads
+// the kernel's VGPR allocation to 129+ to enforce that -- which leaves no room for the second
+// workgroup of a CU whenever both put two waves on one SIMD (measured: one workgroup per CU).
+extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
+
 __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Params prm) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[kOutAlloc];
+  uint8_t* const s_out = s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   __shared__ uint32_t s_cp[2][kListCap + 64];  // dst | offset << 16   (+64: sink slots)
   __shared__ uint8_t s_cl[2][kListCap + 64];   // length 1..64, 0 = skip

@@ -180,6 +180,9 @@ extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
   snappy_hip_ctx* c = new snappy_hip_ctx();
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
+  HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOutAlloc + 8192));
   std::vector<uint32_t> tab(1024), mul(kCrcThreads), so(kSeqLen), ss(kSeqLen);
   build_crc_tables(tab.data(), mul.data());
   build_probe_sequence(so.data(), ss.data());
@@ -450,7 +453,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     }
     {
       LaunchTimer lt(c, s, 0);
-      hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+      hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
+                         kOutAlloc + (getenv("SNAPPY_HIP_ONE_WG") ? 8192 : 0) /* DEBUG: one per CU */, s, dp);
     }
     if (d_stats) {
       unsigned long long h[16];
