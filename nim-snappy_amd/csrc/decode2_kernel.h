@@ -40,9 +40,10 @@ constexpr uint32_t kD2Threads = 320;  // waves 0,1: front end; waves 2-4: resolv
 // (a workgroup's waves are dealt round-robin to the 4 SIMDs: waves 0 and 4 share one, so the
 // two front-end waves must not be 0 and 4)
 constexpr uint32_t kD2Ring = 4096;
-constexpr uint32_t kListCap = 896;  // copy elements per 2 KiB chunk on the fast path (1024 is the
-                                   // format's maximum; such a unit goes to the one-pass kernel)
-constexpr uint32_t kPendBits = 16384;  // window of the pending-byte bitmap (output positions)
+constexpr uint32_t kListCap = 880;   // elements per 2 KiB step that the wide-step (list) mode takes
+constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
+constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
+constexpr uint32_t kPendBits = 16384;  // window of the element-start bitmap (output positions)
 constexpr uint32_t kPendWords = kPendBits / 32;
 constexpr uint32_t kOutSink = kMaxBlockLen + 16; // 64 scratch dwords behind the output window,
 constexpr uint32_t kOutAlloc = kMaxBlockLen + 16 + 256 + 16;  // one per lane (no bank conflicts)
@@ -101,10 +102,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   __shared__ uint32_t s_near[2][2];  // near copies left in each half of list k after compaction
   __shared__ uint32_t s_mode[2];     // list k is resolved through the pending-byte bitmap
   __shared__ uint32_t s_sbase[kMaxFastIn / kChunk + 2];  // output position where step k starts
-  // One bit per output byte (position mod 8192): set while a copy that produces the byte is
-  // still unresolved.  A copy may run as soon as no bit of its source range is set.
+  // One bit per output byte (position mod kPendBits): set where an element of a step that is not
+  // resolved yet starts.  Together with the per-step list of copy offsets this maps every
+  // output byte to its element.
   __shared__ unsigned long long s_pend[kPendWords / 2];
   __shared__ uint32_t s_err;
+  __shared__ uint32_t s_front;                 // every output byte below this position is final
+  __shared__ uint16_t s_gidx[kPendBits / kGroup];  // list slot of the element that covers byte 256 m
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_xdone[1] = 0;
     s_mode[0] = 0;
     s_mode[1] = 0;
+    s_front = 0;
   }
   for (uint32_t i = tid; i < kPendWords / 2; i += kD2Threads) s_pend[i] = 0;
 
@@ -182,9 +187,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   // Unaligned LDS dword accesses cost ~10-20x an aligned one on gfx950 (tools/probes/
   // lds_rates.hip), so sources are read as aligned dwords and re-aligned with a funnel shift,
   // and the destination is written bytewise.
-  auto lean_copy = [&](uint32_t dst, auto rd, uint32_t sh, uint32_t L) {
+  auto lean_copy_pre = [&](uint32_t dst, uint32_t s0, uint32_t s1, uint32_t s2, auto rd, uint32_t sh,
+                           uint32_t L) {
     const uint32_t sh8 = sh * 8;
-    uint32_t s0 = rd(0u), s1 = rd(1u), s2 = rd(2u);
     uint32_t v0 = __funnelshift_r(s0, s1, sh8), v1 = __funnelshift_r(s1, s2, sh8);
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) s_out[L > j ? dst + j : sink + j] = (uint8_t)(v0 >> (8 * j));
@@ -202,6 +207,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       for (uint32_t j = 0; j < 4; j++)
         s_out[L > k + 4 + j ? dst + k + 4 + j : sink + j] = (uint8_t)(v1 >> (8 * j));
     }
+  };
+  auto lean_copy = [&](uint32_t dst, auto rd, uint32_t sh, uint32_t L) {
+    lean_copy_pre(dst, rd(0u), rd(1u), rd(2u), rd, sh, L);
   };
   auto out_al = [&](uint32_t a) -> uint32_t {  // aligned dword that holds s_out[a]
     return *reinterpret_cast<const uint32_t*>(s_out + (a & ~3u));
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
 
   unsigned long long tm_pre = 0, tm_walk = 0, tm_post = 0, tm_bar = 0;
+  uint32_t acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;  // DEBUG counters, flushed once per wave
   for (uint32_t s = 0; s <= n_chunks; s++) {
     if (s_err) break;  // set before the last barrier: every wave sees it here
     const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
@@ -278,33 +287,38 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       const uint32_t c0 = s * kChunk + half * (kChunk / 2);
       const uint32_t e_off = ie & 63;
       const bool had = e_off != kIdxNone;
-      const uint32_t ncopy = had ? (ie >> 6) & 31 : 0;
-      const uint32_t ocopy = (io_cur & 63) != kIdxNone ? (io_cur >> 6) & 31 : 0;
+      const uint32_t nel = had ? (ie >> 6) & 31 : 0;  // elements that start in my region
+      const uint32_t onel = (io_cur & 63) != kIdxNone ? (io_cur >> 6) & 31 : 0;
       uint32_t dst = ie >> 11;
       uint32_t ctot, otot;
-      uint32_t slot = wave_excl_scan(ncopy, lane, &ctot);
-      (void)wave_excl_scan(ocopy, lane, &otot);
-      if (half) slot += otot;  // the first half's copies come first in the list
-      ctot += otot;            // copies of the whole step
-      if (wave == 0 && lane == 0) {
-        s_cnt[buf] = ctot <= kListCap ? ctot : 0;
-        s_xdone[buf] = 0;
-        if (ctot > kListCap) s_err = 2;  // too dense for the fast path: one-pass kernel
-      }
-      if (ctot > kListCap) slot = kListCap;  // all appends of this step go to the sink slots
+      uint32_t slot = wave_excl_scan(nel, lane, &ctot);
+      (void)wave_excl_scan(onel, lane, &otot);
+      if (half) slot += otot;  // the first half's elements come first in the list
+      ctot += otot;            // elements of the whole step
       // output position where this step starts / the next one starts
       const uint32_t cbase = s_sbase[s], cnext = s_sbase[s + 1];
-      // bitmap mode needs this step and the previous one to fit the window
-      const bool bm = cnext - cprev <= kPendBits - 256 && ctot <= kListCap;
-      if (wave == 0 && lane == 0) s_mode[buf] = bm ? 1 : 0;
+      // byte mode: this step and the previous one fit the window of the start bitmap
+      const bool bm = cnext - cprev <= kPendBits - kGroup;
+      // list mode (wide steps = long elements) has a smaller list; denser data than it takes
+      // cannot also be wide, but a hostile stream is handed to the one-pass kernel
+      const bool dense = !bm && ctot > kListCap;
+      if (wave == 0 && lane == 0) {
+        s_cnt[buf] = dense ? 0 : ctot;
+        s_xdone[buf] = 0;
+        s_mode[buf] = bm ? 1 : 0;
+        if (dense) s_err = 2;
+      }
+      if (dense) slot = kListCap;  // all appends of this step go to the sink slots
       cprev = cbase;
+      uint16_t* const o16 = reinterpret_cast<uint16_t*>(s_cp[buf]);  // byte mode: offset per element
+      uint16_t* const sink16 = reinterpret_cast<uint16_t*>(s_out + sink);
 
       const uint32_t rs = c0 + lane * kSub;
       const uint32_t r_end = rs + kSub < n ? rs + kSub : n;
       uint32_t pos = rs + e_off;
       bool live = had && pos < n && !(prm.dbg & 4) && !((prm.dbg & 16) && half == 1) && !((prm.dbg & 32) && half == 0);
       bool big = false;  // a literal longer than 64 bytes ends my region: done below
-      uint32_t big_dst = 0, big_len = 0, big_src = 0;
+      uint32_t big_dst = 0, big_len = 0, big_src = 0, big_slot = 0;
       bool bad = false;
       uint32_t st_trips = 0;
       tm1 = __builtin_amdgcn_s_memtime();
@@ -319,23 +333,26 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         decode_fast(w0 & 0xff, b14, &is_copy, &L, &size, &hdr, &off);
         const bool cpy = live && is_copy;
         const bool lit = live && !is_copy;
-        // ---- copy: append to the list (sink slot when this lane has no copy) ------------------
         const bool bad_off = cpy && (off == 0 || off > dst);  // decoder.nim:112
         bad = bad || bad_off;
-        const uint32_t sl = (cpy && slot < kListCap) ? slot : kListCap + lane;
-        s_cp[buf][sl] = bad_off ? (dst | (1u << 16)) : (dst | (off << 16));
-        // bit 7: source ends below this chunk's output = independent of every unresolved copy
-        const uint32_t far = (dst - off + L <= cbase) ? 0x80u : 0u;
-        s_cl[buf][sl] = bad_off ? 0 : (uint8_t)(L | far);  // length 0 = nothing to do
-        slot += cpy ? 1 : 0;
-        if (bm) {  // mark the bytes this copy will produce as pending
-          uint32_t d0, d1, d2;
-          bits_make(dst, (cpy && !bad_off) ? L : 0, &d0, &d1, &d2);
-          const uint32_t w = (dst & (kPendBits - 1)) >> 5;
-          atomicOr(pw + w, d0);
-          atomicOr(pw + ((w + 1) & (kPendWords - 1)), d1);
-          if (ballot(d2 != 0)) atomicOr(pw + ((w + 2) & (kPendWords - 1)), d2);
+        if (bm) {
+          // ---- byte mode: offset (0 = literal) at the element's slot, start bit at its first
+          // output byte, and its slot at the 256-byte boundary it covers (if any) ----------------
+          *((live && slot < kElemCap) ? o16 + slot : sink16) = (cpy && !bad_off) ? (uint16_t)off : (uint16_t)0;
+          atomicOr(pw + ((dst & (kPendBits - 1)) >> 5), live ? 1u << (dst & 31) : 0u);
+          const uint32_t mb = (dst + kGroup - 1) / kGroup;
+          const bool covers = live && mb * kGroup < dst + L;
+          *(covers ? s_gidx + (mb & (kPendBits / kGroup - 1)) : sink16 + 1) = (uint16_t)slot;
+        } else {
+          // ---- list mode: (dst, offset, length) per element; literals as length 0 ---------------
+          const uint32_t sl = (live && slot < kListCap) ? slot : kListCap + lane;
+          s_cp[buf][sl] = dst | (off << 16);
+          // bit 7: source ends below this chunk's output = independent of every unresolved copy
+          const uint32_t far = (dst - off + L <= cbase) ? 0x80u : 0u;
+          s_cl[buf][sl] = (cpy && !bad_off) ? (uint8_t)(L | far) : (uint8_t)0;  // 0 = nothing to do
         }
+        const uint32_t my_slot = slot;
+        slot += live ? 1 : 0;
         // ---- literal: payload of up to 16 bytes here, up to 64 in the rare loop below -----------
         const uint32_t qs = q + hdr;
         const uint32_t Lw = (lit && L <= 64 && !(prm.dbg & 1)) ? L : 0;  // bytes this lane writes
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           big_dst = dst;
           big_len = L;
           big_src = pos + hdr;
+          big_slot = my_slot;
         }
         dst += live ? L : 0;
         pos += live ? size : 0;
@@ -359,6 +377,11 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const uint32_t eL = readlane(big_len, e);
         const uint32_t ed = readlane(big_dst, e);
         const uint32_t es = readlane(big_src, e);
+        if (bm) {  // every 256-byte boundary the literal covers maps to its slot
+          const uint32_t eslot = readlane(big_slot, e);
+          for (uint32_t m = (ed + kGroup - 1) / kGroup + lane; m * kGroup < ed + eL; m += 64)
+            s_gidx[m & (kPendBits / kGroup - 1)] = (uint16_t)eslot;
+        }
         // 16 bytes per lane and pass, four passes in flight
         const uint32_t body = eL & ~15u;
         for (uint32_t i = lane * 16; i < body; i += 4 * 1024) {
@@ -379,80 +402,114 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (body + lane < eL) s_out[ed + body + lane] = in0[es + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
-      if (prm.stats && lane == 0 && wave == 0) {
-        atomicAdd(&prm.stats[4], (unsigned long long)st_trips);
-        atomicAdd(&prm.stats[5], 1ull);
-        atomicAdd(&prm.stats[6], (unsigned long long)(bm ? 1 : 0));
-      }
+      acc_a += st_trips;
+      acc_b += 1;
+      acc_c += bm ? 1 : 0;
     } else if (wave >= 2 && s >= 1 && s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
-      // =================================== resolver pool ==========================================
-      // Three waves share the previous step's list (batches round-robin).  Dependencies are
-      // exact: a copy runs when no byte of its source is still pending, whichever wave owns the
-      // copies it waits for.  The lowest unresolved copy of the list is always runnable and its
-      // owner is always working on its batch, so the pool cannot dead-lock.
+      // =================================== byte-mode resolver ======================================
+      // The three waves take the 256-byte groups of the previous step's output in turn, one
+      // aligned dword per lane.  A byte finds its element by counting start bits from the group's
+      // first byte (whose element the front end recorded in s_gidx); a copy byte's source is
+      // "own position - offset".  Sources inside the group are followed to a byte that is final
+      // (pointer doubling through a small LDS array); sources below the group must lie under the
+      // frontier s_front, which the groups advance strictly in order.
       const uint32_t buf = (s - 1) & 1;
-      const uint32_t count = s_cnt[buf];
-      for (uint32_t b0 = (wave - 2) * 64; b0 < count; b0 += 192) {
-        const uint32_t i = b0 + lane;
-        const uint32_t lf = i < count ? s_cl[buf][i] : 0;
-        const uint32_t e = s_cp[buf][i];
-        const uint32_t len = lf & 0x7f;
-        const bool act = len != 0;
-        const bool far = (lf & 0x80) != 0;
-        const uint32_t dst = e & 0xffff, off = e >> 16;
-        const uint32_t src = act ? dst - off : 0;
-        const bool ovl = act && off < len;  // self-overlapping: the source is the `off` bytes below dst
-        uint32_t m0, m1, m2, q0, q1, q2;
-        bits_make(dst, len, &m0, &m1, &m2);             // the bytes I produce
-        const uint32_t slen = ovl ? off : len;
-        bits_make(src, slen, &q0, &q1, &q2);            // the bytes I need
-        const uint32_t bw = (dst & (kPendBits - 1)) >> 5, sw = (src & (kPendBits - 1)) >> 5;
-        const bool wide = ballot(m2 != 0 || q2 != 0) != 0;
-        uint64_t pend = ballot(act);
-        uint32_t st_rounds = 0, st_spins = 0;
-        while (pend) {
-          st_rounds++;
-          uint32_t busy =
-              (__hip_atomic_load(pw + sw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q0) |
-              (__hip_atomic_load(pw + ((sw + 1) & (kPendWords - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q1);
-          if (wide)
-            busy |= __hip_atomic_load(pw + ((sw + 2) & (kPendWords - 1)), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & q2;
-          const bool rdy = ((pend >> lane) & 1) && (far || busy == 0);
-          const uint64_t rm = ballot(rdy);
-          if (rm == 0) {  // everything left waits for another wave
-            st_spins++;
-            if (st_spins > 400000) {  // cannot happen on a consistent index; never hang the GPU
-              if (lane == 0) atomicOr(&s_err, 4u);
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          lean_copy(dst, [&](uint32_t k) { return out_al(src + 4 * k); }, src & 3, (rdy && !ovl) ? len : 0);
-          if (ballot(rdy && ovl)) {  // rare: replicate the pattern of `off` bytes
-            if (rdy && ovl) {
-              uint32_t j = 0;
-              for (uint32_t k = 0; k < len; k++) {
-                s_out[dst + k] = s_out[src + j];
-                j = j + 1 == off ? 0 : j + 1;
-              }
-            }
-          }
-          wave_fence();
-          __hip_atomic_fetch_and(pw + bw, rdy ? ~m0 : ~0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_and(pw + ((bw + 1) & (kPendWords - 1)), rdy ? ~m1 : ~0u, __ATOMIC_RELEASE,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (wide)
-            __hip_atomic_fetch_and(pw + ((bw + 2) & (kPendWords - 1)), rdy ? ~m2 : ~0u, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-          pend &= ~rm;
+      const uint32_t cb = s_sbase[s - 1], cn = s_sbase[s];
+      const uint16_t* const o16 = reinterpret_cast<const uint16_t*>(s_cp[buf]);
+      uint16_t* const r16 = reinterpret_cast<uint16_t*>(s_cp[buf]) + (kElemCap + 64) + (wave - 2) * kGroup;
+      auto cbar = [] { asm volatile("" ::: "memory"); };
+      uint32_t front = cb;  // what I know of s_front
+      for (uint32_t g = (cb & ~(kGroup - 1)) + (wave - 2) * kGroup; g < cn; g += 3 * kGroup) {
+        acc_c++;
+        const uint32_t p = g + 4 * lane;
+        const uint32_t wbits = pw[(p & (kPendBits - 1)) >> 5];
+        // my bytes that belong to this step: [lo, hi) of 0..4
+        const uint32_t lo = p >= cb ? 0 : (cb - p < 4 ? cb - p : 4);
+        const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
+        const uint32_t rmask = ((1u << hi) - 1) & ~((1u << lo) - 1);
+        const uint32_t sb = (wbits >> (p & 31)) & rmask;
+        // the element that covers byte g is E0; a start bit AT g is that element itself
+        const uint32_t cbits = sb & ~((lane == 0 && g >= cb) ? 1u : 0u);
+        const uint32_t E0 = g > cb ? (uint32_t)s_gidx[(g / kGroup) & (kPendBits / kGroup - 1)]
+                                   : (g == cb ? 0u : 0xffffffffu);
+        uint32_t tot;
+        const uint32_t excl = wave_excl_scan((uint32_t)__builtin_popcount(cbits), lane, &tot);
+        uint32_t sp[4];
+        bool cp[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const bool in = (rmask >> j) & 1;
+          const uint32_t idx = E0 + excl + (uint32_t)__builtin_popcount(cbits & ((2u << j) - 1));
+          const uint32_t off = o16[in ? idx : 0];
+          cp[j] = in && off != 0;
+          sp[j] = p + j - (cp[j] ? off : 0);
         }
-        if (prm.stats && lane == 0) {
-          atomicAdd(&prm.stats[0], (unsigned long long)st_rounds);
-          atomicAdd(&prm.stats[1], (unsigned long long)st_spins);
-          atomicAdd(&prm.stats[2], 1ull);
-          atomicAdd(&prm.stats[3], (unsigned long long)__builtin_popcountll(ballot(act)));
+        // ---- sources inside my own group: follow them to a final byte ----------------------------
+        if (ballot((cp[0] && sp[0] >= g) || (cp[1] && sp[1] >= g) || (cp[2] && sp[2] >= g) ||
+                   (cp[3] && sp[3] >= g))) {
+          for (uint32_t it = 0; it < 10; it++) {
+            acc_b++;
+            cbar();
+            *reinterpret_cast<uint2*>(r16 + 4 * lane) = make_uint2(sp[0] | (sp[1] << 16), sp[2] | (sp[3] << 16));
+            cbar();
+            bool changed = false;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+              const bool dep = cp[j] && sp[j] >= g;
+              const uint32_t t = r16[dep ? sp[j] - g : 0];
+              changed = changed || (dep && t != sp[j]);
+              sp[j] = dep ? t : sp[j];
+            }
+            cbar();
+            if (!ballot(changed)) break;
+          }
         }
+        // ---- sources below the group must be final ------------------------------------------------
+        for (uint32_t spin = 0;; spin++) {
+          const bool wait = (cp[0] && sp[0] < g && sp[0] >= front) || (cp[1] && sp[1] < g && sp[1] >= front) ||
+                            (cp[2] && sp[2] < g && sp[2] >= front) || (cp[3] && sp[3] < g && sp[3] >= front);
+          if (!ballot(wait)) break;
+          acc_a++;
+          if (spin > 400000) {  // cannot happen on a consistent index; never hang the GPU
+            if (lane == 0) atomicOr(&s_err, 4u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          cbar();
+        }
+        cbar();
+        // ---- gather and store -----------------------------------------------------------------------
+        const uint32_t v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
+                           ((uint32_t)s_out[sp[3]] << 24);
+        const bool anyc = cp[0] || cp[1] || cp[2] || cp[3];
+        const bool full = rmask == 15;  // the whole dword is this step's: its other bytes are final
+        *reinterpret_cast<uint32_t*>(s_out + ((full && anyc) ? p : sink)) = v;
+        if (ballot(!full && anyc)) {  // the step's first and last dword: bytewise
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++) s_out[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
+        }
+        // ---- clear my start bits, then advance the frontier in order --------------------------------
+        if ((lane & 7) == 0) {
+          const uint32_t l32 = p >= cb ? 0 : (cb - p < 32 ? cb - p : 32);
+          const uint32_t h32 = p + 32 <= cn ? 32 : (cn > p ? cn - p : 0);
+          const uint32_t m32 = (uint32_t)(((1ull << h32) - 1) & ~((1ull << l32) - 1));
+          atomicAnd(pw + ((p & (kPendBits - 1)) >> 5), ~m32);
+        }
+        cbar();
+        const uint32_t expect = g > cb ? g : cb;
+        for (uint32_t spin = 0; front != expect; spin++) {
+          if (spin > 400000) {
+            if (lane == 0) atomicOr(&s_err, 4u);
+            break;
+          }
+          front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          cbar();
+          if (front != expect) __builtin_amdgcn_s_sleep(1);
+        }
+        front = g + kGroup < cn ? g + kGroup : cn;
+        cbar();
+        if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else if (wave >= 3 && s >= 1 && !(prm.dbg & 2)) {
       // =================================== far copies ============================================
@@ -566,18 +623,34 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           wave_fence();
         }
       }
+      if (lane == 0) s_front = s_sbase[s];  // what byte mode expects to find
     }
     const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
     // Workgroup barrier for LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait
     // for the global prefetches that are meant to stay in flight across the barrier.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
-    if (wave == 0) {
+    if (wave == 0 || wave == 2) {
       tm_pre += tm1 - tm0;
       tm_walk += tm2 - tm1;
       tm_post += tm3 - tm2;
       tm_bar += tm4 - tm3;
     }
+  }
+  if (prm.stats && lane == 0 && wave >= 2) {
+    atomicAdd(&prm.stats[0], (unsigned long long)acc_a);
+    atomicAdd(&prm.stats[1], (unsigned long long)acc_b);
+    atomicAdd(&prm.stats[2], (unsigned long long)acc_c);
+    atomicAdd(&prm.stats[3], (unsigned long long)acc_d);
+  }
+  if (prm.stats && tid == 0) {
+    atomicAdd(&prm.stats[4], (unsigned long long)acc_a);
+    atomicAdd(&prm.stats[5], (unsigned long long)acc_b);
+    atomicAdd(&prm.stats[6], (unsigned long long)acc_c);
+  }
+  if (prm.stats && tid == 128) {
+    atomicAdd(&prm.stats[11], tm_post);  // pool wave: work
+    atomicAdd(&prm.stats[12], tm_bar);   // pool wave: waiting at the step barrier
   }
   if (prm.stats && tid == 0) {
     atomicAdd(&prm.stats[7], tm_pre);

@@ -8,7 +8,7 @@
 //
 //   1. Right-to-left pass, one 32-byte region per lane: for EVERY byte k of the region compute
 //      "if an element started here, where does the element chain leave my region, how many
-//      output bytes and how many copy elements does it produce on the way".  Going right to
+//      output bytes and how many elements does it hold on the way".  Going right to
 //      left, position k only needs its own element and the already finished entry of k+size,
 //      so all 64 lanes run 32 independent steps (table in LDS, 33-dword row stride = no bank
 //      conflicts).
@@ -25,7 +25,7 @@
 //      stream its own lane.
 //
 // Index entry per 16 bytes of stream (u32):  [0:6) offset of the first element that starts in
-// them (32 = none)  [6:11) copy elements that start in them  [11:28) output position of that
+// them (32 = none)  [6:11) elements that start in them  [11:28) output position of that
 // first element.
 //
 // All input-side checks of decodeAllTags (truncated elements, the 61-byte rule of
@@ -51,11 +51,11 @@ constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's r
 // snappy/codec.nim:217); longer units go to the one-pass kernel.
 constexpr uint32_t kMaxFastIn = 98304;
 
-__device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t ncopy, uint32_t outsum) {
-  return exit_rel | (ncopy << 10) | (outsum << 15);
+__device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t nelem, uint32_t outsum) {
+  return exit_rel | (nelem << 10) | (outsum << 15);
 }
 __device__ __forceinline__ uint32_t t_exit(uint32_t t) { return t & 1023; }
-__device__ __forceinline__ uint32_t t_ncopy(uint32_t t) { return (t >> 10) & 31; }
+__device__ __forceinline__ uint32_t t_nelem(uint32_t t) { return (t >> 10) & 31; }
 __device__ __forceinline__ uint32_t t_out(uint32_t t) { return t >> 15; }
 // value of lane-1 (0 for lane 0) through DPP, no LDS round trip
 __device__ __forceinline__ uint32_t lane_prev_u32(uint32_t v) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
 
   for (uint32_t c0 = 0; c0 < n && !ended; c0 += kChunk) {
     const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position
-    uint32_t entry_off = kIdxNone, out_here = 0, ncopy_here = 0;
+    uint32_t entry_off = kIdxNone, out_here = 0, nelem_here = 0;
 
     if (entry_abs < c0 + kChunk) {  // otherwise a long literal covers the whole chunk
       // ---- my 32 region bytes + 8 bytes lookahead, from 16-byte aligned loads ---------------
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
             szb = size < 255 ? size : 255;
             const uint32_t nx = (uint32_t)k + size;  // ok => size <= rem + 1: no wrap
             if (nx >= kRegion) {
-              t = t_pack(nx < kExitFar ? nx : kExitFar + (uint32_t)k, is_copy ? 1 : 0, Ls);
+              t = t_pack(nx < kExitFar ? nx : kExitFar + (uint32_t)k, 1, Ls);
             } else {
               const uint32_t tn = s_tab[row + nx];
               if (t_exit(tn) == kExitErr) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
               } else {
                 uint32_t o = Ls + t_out(tn);
                 if (o > kOutSat) o = kOutSat;
-                t = t_pack(t_exit(tn), t_ncopy(tn) + (is_copy ? 1 : 0), o);
+                t = t_pack(t_exit(tn), t_nelem(tn) + 1, o);
               }
             }
           }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       if (has && in_abs < n) {  // in_abs == n is the end of the stream, not an element
         entry_off = in_abs - rs;
         out_here = t_out(tv);
-        ncopy_here = t_ncopy(tv);
+        nelem_here = t_nelem(tv);
       }
       ended = ballot(has && t_exit(tv) == kExitEnd) != 0;
       entry_abs = readlane(out_abs, 63);
@@ -316,14 +316,14 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       if (entry_off != kIdxNone && pw < kRegion && rs + pw < n) {  // an element in the second half
         const uint32_t t2 = s_tab[row + pw];
         out_second = t_out(t2);
-        nc_second = t_ncopy(t2);
+        nc_second = t_nelem(t2);
         e1 = pw - kSub;
         nc1 = nc_second;
         pos1 = pos0 + (out_here - out_second);
       }
       if (entry_off < kSub) {
         e0 = entry_off;
-        nc0 = ncopy_here - nc_second;
+        nc0 = nelem_here - nc_second;
       }
     }
     if (rs < n) {
@@ -369,7 +369,7 @@ __global__ void verify_index_kernel(IndexParams prm, uint32_t* report) {
         bool c;
         uint32_t L, size, hdr, off;
         decode_element(in0[pos], b, 0xffffffffu, &c, &L, &size, &hdr, &off);
-        nc += c ? 1 : 0;
+        nc += 1;
         dst += L;
         pos += size;
       }
