@@ -36,15 +36,20 @@
 
 namespace snappy_hip {
 
-constexpr uint32_t kD2Threads = 320;  // waves 0,1: front end; waves 2-4: resolver pool
+constexpr uint32_t kD2Threads = 512;  // waves 0,1: front end; waves 2-7: resolvers
+constexpr uint32_t kD2Pool = kD2Threads / 64 - 2;
 // (a workgroup's waves are dealt round-robin to the 4 SIMDs: waves 0 and 4 share one, so the
 // two front-end waves must not be 0 and 4)
 constexpr uint32_t kD2Ring = 4096;
-constexpr uint32_t kListCap = 880;   // elements per 2 KiB step that the wide-step (list) mode takes
+constexpr uint32_t kListCap = 704;   // elements per 2 KiB step that the wide-step (list) mode takes
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
 constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
 constexpr uint32_t kPendBits = 16384;  // window of the element-start bitmap (output positions)
 constexpr uint32_t kPendWords = kPendBits / 32;
+// byte mode keeps kElemCap u16 offsets in a list buffer and two waves' scratch behind them; one
+// more wave's scratch goes into the (then unused) length array
+static_assert((kListCap + 64) * 4 >= kElemCap * 2 + 2 * kGroup * 2, "list buffer too small for byte mode");
+static_assert(kListCap + 64 >= kGroup * 2 && (kListCap + 64) % 8 == 0, "length array too small for scratch");
 constexpr uint32_t kOutSink = kMaxBlockLen + 16; // 64 scratch dwords behind the output window,
 constexpr uint32_t kOutAlloc = kMaxBlockLen + 16 + 256 + 16;  // one per lane (no bank conflicts)
 
@@ -95,8 +100,8 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Params prm) {
   uint8_t* const s_out = s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
-  __shared__ uint32_t s_cp[2][kListCap + 64];  // dst | offset << 16   (+64: sink slots)
-  __shared__ uint8_t s_cl[2][kListCap + 64];   // length 1..64, 0 = skip
+  __shared__ __attribute__((aligned(8))) uint32_t s_cp[2][kListCap + 64];  // dst | offset << 16   (+64: sink slots)
+  __shared__ __attribute__((aligned(8))) uint8_t s_cl[2][kListCap + 64];   // length 1..64, 0 = skip
   __shared__ uint32_t s_cnt[2];
   __shared__ uint32_t s_xdone[2];  // far-copy waves finished with list k
   __shared__ uint32_t s_near[2][2];  // near copies left in each half of list k after compaction
@@ -107,6 +112,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   // output byte to its element.
   __shared__ unsigned long long s_pend[kPendWords / 2];
   __shared__ uint32_t s_err;
+  // pointer-doubling scratch of resolver waves 2-4; waves 5-7 use the parts of their step's list
+  // buffers that byte mode leaves free
+  __shared__ __attribute__((aligned(8))) uint16_t s_r16[3][kGroup];
   __shared__ uint32_t s_front;                 // every output byte below this position is final
   __shared__ uint16_t s_gidx[kPendBits / kGroup];  // list slot of the element that covers byte 256 m
 
@@ -416,13 +424,16 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       const uint32_t buf = (s - 1) & 1;
       const uint32_t cb = s_sbase[s - 1], cn = s_sbase[s];
       const uint16_t* const o16 = reinterpret_cast<const uint16_t*>(s_cp[buf]);
-      uint16_t* const r16 = reinterpret_cast<uint16_t*>(s_cp[buf]) + (kElemCap + 64) + (wave - 2) * kGroup;
+      uint16_t* const r16 = wave < 5 ? s_r16[wave - 2]
+                            : wave < 7 ? reinterpret_cast<uint16_t*>(s_cp[buf]) + kElemCap + (wave - 5) * kGroup
+                                       : reinterpret_cast<uint16_t*>(s_cl[buf]);
       auto cbar = [] { asm volatile("" ::: "memory"); };
       uint32_t front = cb;  // what I know of s_front
-      for (uint32_t g = (cb & ~(kGroup - 1)) + (wave - 2) * kGroup; g < cn; g += 3 * kGroup) {
+      for (uint32_t g = (cb & ~(kGroup - 1)) + (wave - 2) * kGroup; g < cn; g += kD2Pool * kGroup) {
         acc_c++;
         const uint32_t p = g + 4 * lane;
         const uint32_t wbits = pw[(p & (kPendBits - 1)) >> 5];
+        front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // my bytes that belong to this step: [lo, hi) of 0..4
         const uint32_t lo = p >= cb ? 0 : (cb - p < 4 ? cb - p : 4);
         const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
@@ -449,6 +460,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
                    (cp[3] && sp[3] >= g))) {
           for (uint32_t it = 0; it < 10; it++) {
             acc_b++;
+            // every byte publishes its pointer (final bytes point to themselves) and takes over
+            // the pointer of the byte it points to: the chain length halves
             cbar();
             *reinterpret_cast<uint2*>(r16 + 4 * lane) = make_uint2(sp[0] | (sp[1] << 16), sp[2] | (sp[3] << 16));
             cbar();
@@ -464,24 +477,37 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
             if (!ballot(changed)) break;
           }
         }
-        // ---- sources below the group must be final ------------------------------------------------
-        for (uint32_t spin = 0;; spin++) {
-          const bool wait = (cp[0] && sp[0] < g && sp[0] >= front) || (cp[1] && sp[1] < g && sp[1] >= front) ||
-                            (cp[2] && sp[2] < g && sp[2] >= front) || (cp[3] && sp[3] < g && sp[3] >= front);
-          if (!ballot(wait)) break;
+        // ---- my start bits are consumed (every lane's read of them was issued above) -----------------
+        if ((lane & 7) == 0) {
+          const uint32_t l32 = p >= cb ? 0 : (cb - p < 32 ? cb - p : 32);
+          const uint32_t h32 = p + 32 <= cn ? 32 : (cn > p ? cn - p : 0);
+          const uint32_t m32 = (uint32_t)(((1ull << h32) - 1) & ~((1ull << l32) - 1));
+          atomicAnd(pw + ((p & (kPendBits - 1)) >> 5), ~m32);
+        }
+        // ---- gather early; bytes whose source was not final yet are fetched again below ------------
+        const bool stale = (cp[0] && sp[0] < g && sp[0] >= front) || (cp[1] && sp[1] < g && sp[1] >= front) ||
+                           (cp[2] && sp[2] < g && sp[2] >= front) || (cp[3] && sp[3] < g && sp[3] >= front);
+        cbar();
+        uint32_t v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
+                     ((uint32_t)s_out[sp[3]] << 24);
+        cbar();
+        // ---- my turn: every group below mine has published, i.e. everything below g is final ------
+        const uint32_t expect = g > cb ? g : cb;
+        for (uint32_t spin = 0; front != expect; spin++) {
           acc_a++;
-          if (spin > 400000) {  // cannot happen on a consistent index; never hang the GPU
+          if ((spin & 1023) == 1023 && (spin > 400000 || s_err != 0)) {
+            // cannot happen on a consistent index; never hang the GPU
             if (lane == 0) atomicOr(&s_err, 4u);
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
           front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           cbar();
         }
-        cbar();
-        // ---- gather and store -----------------------------------------------------------------------
-        const uint32_t v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
-                           ((uint32_t)s_out[sp[3]] << 24);
+        if (ballot(stale)) {
+          acc_d++;
+          v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
+              ((uint32_t)s_out[sp[3]] << 24);
+        }
         const bool anyc = cp[0] || cp[1] || cp[2] || cp[3];
         const bool full = rmask == 15;  // the whole dword is this step's: its other bytes are final
         *reinterpret_cast<uint32_t*>(s_out + ((full && anyc) ? p : sink)) = v;
@@ -489,29 +515,11 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 #pragma unroll
           for (uint32_t j = 0; j < 4; j++) s_out[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
         }
-        // ---- clear my start bits, then advance the frontier in order --------------------------------
-        if ((lane & 7) == 0) {
-          const uint32_t l32 = p >= cb ? 0 : (cb - p < 32 ? cb - p : 32);
-          const uint32_t h32 = p + 32 <= cn ? 32 : (cn > p ? cn - p : 0);
-          const uint32_t m32 = (uint32_t)(((1ull << h32) - 1) & ~((1ull << l32) - 1));
-          atomicAnd(pw + ((p & (kPendBits - 1)) >> 5), ~m32);
-        }
-        cbar();
-        const uint32_t expect = g > cb ? g : cb;
-        for (uint32_t spin = 0; front != expect; spin++) {
-          if (spin > 400000) {
-            if (lane == 0) atomicOr(&s_err, 4u);
-            break;
-          }
-          front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          cbar();
-          if (front != expect) __builtin_amdgcn_s_sleep(1);
-        }
         front = g + kGroup < cn ? g + kGroup : cn;
         cbar();
         if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-    } else if (wave >= 3 && s >= 1 && !(prm.dbg & 2)) {
+    } else if ((wave == 3 || wave == 4) && s >= 1 && !s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
       // =================================== far copies ============================================
       const uint32_t buf = (s - 1) & 1;
       const uint32_t count = s_cnt[buf];
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       if (lane == 0) s_near[buf][wave - 3] = wpos - seg0;
       wave_fence();
       if (lane == 0) atomicAdd(&s_xdone[buf], 1u);
-    } else if (wave == 2 && s >= 1 && !(prm.dbg & 2)) {
+    } else if (wave == 2 && s >= 1 && !s_mode[(s - 1) & 1] && !(prm.dbg & 2)) {
       // =================================== resolver ==============================================
       for (uint32_t spin = 0; __hip_atomic_load(&s_xdone[(s - 1) & 1], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_WORKGROUP) < 2 && spin < 400000; spin++)
@@ -634,6 +642,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       tm_pre += tm1 - tm0;
       tm_walk += tm2 - tm1;
       tm_post += tm3 - tm2;
+      if (wave == 2 && s >= 1 && !s_mode[(s - 1) & 1]) {  // list-mode share of the resolver's time
+        tm_walk += tm3 - tm2;
+        tm_pre += 1;
+      }
       tm_bar += tm4 - tm3;
     }
   }
@@ -651,6 +663,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   if (prm.stats && tid == 128) {
     atomicAdd(&prm.stats[11], tm_post);  // pool wave: work
     atomicAdd(&prm.stats[12], tm_bar);   // pool wave: waiting at the step barrier
+    atomicAdd(&prm.stats[13], tm_walk);  // pool wave: work in list-mode steps
+    atomicAdd(&prm.stats[14], tm_pre);   // list-mode steps
   }
   if (prm.stats && tid == 0) {
     atomicAdd(&prm.stats[7], tm_pre);

@@ -464,7 +464,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
               h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
       fprintf(stderr, "STATS wave0 ticks per step: pre %.0f walk %.0f post %.0f barrier %.0f\n", (double)h[7] / h[5],
               (double)h[8] / h[5], (double)h[9] / h[5], (double)h[10] / h[5]);
-      fprintf(stderr, "STATS wave2 ticks per step: work %.0f barrier %.0f\n", (double)h[11] / h[5], (double)h[12] / h[5]);
+      fprintf(stderr, "STATS wave2 ticks per step: work %.0f barrier %.0f; list-mode steps %llu, ticks each %.0f\n", (double)h[11] / h[5], (double)h[12] / h[5], h[14], (double)h[13] / (h[14] ? h[14] : 1));
       (void)hipFree(d_stats);
     }
   }
