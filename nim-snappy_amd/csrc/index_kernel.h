@@ -49,7 +49,7 @@ constexpr uint32_t kSub = 16;                       // stream bytes per index en
 constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's row in the size table
 // Longest tag stream the indexed path takes (a valid 64 KiB block needs at most 76 490 bytes,
 // snappy/codec.nim:217); longer units go to the one-pass kernel.
-constexpr uint32_t kMaxFastIn = 98304;
+constexpr uint32_t kMaxFastIn = 81920;  // >= maxCompressedLen(65536) = 76490: 40 steps of 2 KiB
 
 __device__ __forceinline__ uint32_t t_pack(uint32_t exit_rel, uint32_t nelem, uint32_t outsum) {
   return exit_rel | (nelem << 10) | (outsum << 15);

@@ -460,11 +460,11 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       unsigned long long h[16];
       HIP_TRY(hipMemcpyAsync(h, d_stats, 128, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      fprintf(stderr, "STATS pool: rounds %llu spins %llu batches %llu copies %llu | front: trips %llu steps %llu bitmap-steps %llu\n",
-              h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
-      fprintf(stderr, "STATS wave0 ticks per step: pre %.0f walk %.0f post %.0f barrier %.0f\n", (double)h[7] / h[5],
-              (double)h[8] / h[5], (double)h[9] / h[5], (double)h[10] / h[5]);
-      fprintf(stderr, "STATS wave2 ticks per step: work %.0f barrier %.0f; list-mode steps %llu, ticks each %.0f\n", (double)h[11] / h[5], (double)h[12] / h[5], h[14], (double)h[13] / (h[14] ? h[14] : 1));
+      const double st = h[1] ? (double)h[1] : 1.0;  // front-end steps (wave 0)
+      fprintf(stderr, "STATS front end: steps %llu trips/step %.2f work %.0f barrier %.0f ticks/step\n", h[1],
+              h[0] / st, h[4] / st, h[5] / st);
+      fprintf(stderr, "STATS resolver wave 2: groups/step %.2f doubling rounds/group %.2f work %.0f barrier %.0f ticks/step\n",
+              h[10] / st, h[10] ? (double)h[11] / h[10] : 0.0, h[12] / st, h[13] / st);
       (void)hipFree(d_stats);
     }
   }
