@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
-  const uint32_t wave = tid >> 6;
+  const uint32_t wave = readfirst(tid >> 6);  // (scalar register: wave-uniform by construction)
   const uint64_t u = blockIdx.x;
   if (u >= prm.n_units) return;
   if (prm.status[u] != kOk) return;  // the index pass already decided this unit
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     } else if (!fe && s >= 1 && !(prm.dbg & 2)) {
       // =================================== resolvers ===============================================
       const uint32_t buf = (s - 1) & 1;
-      const uint32_t cb = s_sbase[s - 1], cn = s_sbase[s];
-      const uint32_t count = s_cnt[buf];
+      const uint32_t cb = readfirst(s_sbase[s - 1]), cn = readfirst(s_sbase[s]);
+      const uint32_t count = readfirst(s_cnt[buf]);
       const uint16_t* const o16 = s_off[buf];
       const uint16_t* const d16 = s_dst[buf];
       uint16_t* const r16 = s_r16[wave - 2];
@@ -333,18 +333,19 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       const uint32_t gfirst = cb & ~(kGroup - 1);
       // a group in the middle of one long literal holds no copy (the front end flags the
       // boundaries such a literal covers); nobody works on it, the group before it publishes it
-      auto is_skip = [&](uint32_t gg) -> bool {  // gg > cb
+      auto is_skip = [&](uint32_t gg) -> bool {  // gg > cb (per lane)
         const uint32_t a = s_gidx[gg / kGroup];
         const uint32_t b2 = s_gidx[(gg / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
         return (a & 0x8000u) && gg + kGroup < cn && a == b2;
       };
       uint32_t front = cb;  // what I know of s_front
       for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn; g += kD2Pool * kGroup) {
-        const uint32_t ge = g > cb ? (uint32_t)s_gidx[g / kGroup] : 0;
-        if (g > cb && is_skip(g)) continue;  // (wave-uniform)
+        const uint32_t ge = g > cb ? readfirst((uint32_t)s_gidx[g / kGroup]) : 0;
+        if (g > cb && readfirst(is_skip(g) ? 1u : 0u)) continue;
         acc_c++;
         const uint32_t p = g + 4 * lane;
-        front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (front > (g > cb ? g : cb)) continue;  // a run extension (below) has covered my group
         // the element that covers byte g is E0 (none in the step's first group when it starts
         // inside it); the elements after it that start inside the group set their start bits
         const uint32_t E0 = g > cb ? (ge & 0x7fffu) : (g == cb ? 0u : 0xffffffffu);
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const uint32_t cbits = (wbits >> ((4 * lane) & 31)) & rmask;
         uint32_t tot;
         const uint32_t excl = wave_excl_scan((uint32_t)__builtin_popcount(cbits), lane, &tot);
-        uint32_t sp[4];
+        uint32_t sp[4], offj[4];
         bool cp[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
@@ -375,30 +376,56 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           const uint32_t ei = E0 + excl + (uint32_t)__builtin_popcount(cbits & ((2u << j) - 1));
           const uint32_t off = o16[in ? ei : 0];
           cp[j] = in && off != 0;
-          sp[j] = p + j - (cp[j] ? off : 0);
+          offj[j] = cp[j] ? off : 0;
+          sp[j] = p + j - offj[j];
         }
         const bool anyc = cp[0] || cp[1] || cp[2] || cp[3];
+        // A group that is one run of copies with one offset (how the encoder splits a long match,
+        // encoder.nim:97-112): if the run goes on, I will also do the whole groups that follow
+        // inside it, 256 bytes per trip, once it is my turn.  run_end = first byte after them.
+        // (only groups of few, long elements are examined: tot = element starts in the group)
+        uint32_t run_off = 0, run_end = 0;
+#ifndef SNAPPY_NO_RUN_EXT
+        if (__builtin_expect(tot <= 8 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0 &&
+            ballot(offj[0] != run_off || offj[1] != run_off || offj[2] != run_off || offj[3] != run_off) == 0, 0)) {
+          uint32_t R = cn;
+          for (uint32_t e = E0 + tot + 1 + lane;; e += 64) {  // elements after those of my group
+            const uint32_t oo = e < count ? (uint32_t)o16[e] : 0;
+            const uint64_t mm = ballot(oo != run_off);
+            if (mm) {
+              const uint32_t ef = readfirst(e) + ctz64(mm);
+              if (ef < count) R = readfirst((uint32_t)d16[ef]);
+              break;
+            }
+          }
+          run_end = R & ~(kGroup - 1);
+        }
+#endif
         const bool work = ballot(anyc) != 0;  // (a group of literals only has nothing to do)
         // ---- sources inside my own group: follow them to a final byte ----------------------------
-        if (ballot((cp[0] && sp[0] >= g) || (cp[1] && sp[1] >= g) || (cp[2] && sp[2] >= g) ||
-                   (cp[3] && sp[3] >= g))) {
+        bool dep[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) dep[j] = cp[j] && sp[j] >= g;
+        if (ballot(dep[0] || dep[1] || dep[2] || dep[3])) {
           for (uint32_t it = 0; it < 10; it++) {
             acc_d++;
-            // every byte publishes its pointer (final bytes point to themselves) and takes over
-            // the pointer of the byte it points to: the chain length halves
+            // every copy byte publishes its pointer, every other byte "I am final" (0xffff, never a
+            // source position); a byte takes over the pointer of the copy byte it points to: the
+            // chain length halves per round
             cbar();
-            *reinterpret_cast<uint2*>(r16 + 4 * lane) = make_uint2(sp[0] | (sp[1] << 16), sp[2] | (sp[3] << 16));
+            *reinterpret_cast<uint2*>(r16 + 4 * lane) =
+                make_uint2((cp[0] ? sp[0] : 0xffffu) | ((cp[1] ? sp[1] : 0xffffu) << 16),
+                           (cp[2] ? sp[2] : 0xffffu) | ((cp[3] ? sp[3] : 0xffffu) << 16));
             cbar();
-            bool changed = false;
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-              const bool dep = cp[j] && sp[j] >= g;
-              const uint32_t t = r16[dep ? sp[j] - g : 0];
-              changed = changed || (dep && t != sp[j]);
-              sp[j] = dep ? t : sp[j];
+              const uint32_t t = r16[dep[j] ? sp[j] - g : 0];
+              const bool fin = t == 0xffffu;  // my source is a final byte of the group
+              sp[j] = (dep[j] && !fin) ? t : sp[j];
+              dep[j] = dep[j] && !fin && t >= g;
             }
             cbar();
-            if (!ballot(changed)) break;
+            if (!ballot(dep[0] || dep[1] || dep[2] || dep[3])) break;
           }
         }
         // ---- gather early; bytes whose source was not final yet are fetched again below ------------
@@ -421,15 +448,16 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         cbar();
         // ---- my turn: every group below mine has published, i.e. everything below g is final ------
         const uint32_t expect = g > cb ? g : cb;
-        for (uint32_t spin = 0; front != expect; spin++) {
+        for (uint32_t spin = 0; front < expect; spin++) {
           if ((spin & 1023) == 1023 && (spin > 400000 || s_err != 0)) {
             // cannot happen on a consistent index; never hang the GPU
             if (lane == 0) atomicOr(&s_err, 4u);
             break;
           }
-          front = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           cbar();
         }
+        if (front > expect) continue;  // covered by a run extension meanwhile
         if (work) {
           if (ballot(stale)) {
             v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
@@ -445,7 +473,32 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
             for (uint32_t j = 0; j < 4; j++) s_out[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
           }
         }
-        front = g + kGroup * (1 + nskip);
+        if (__builtin_expect(run_end > g + kGroup, 0)) {
+          // ---- run extension: out[x] = out[x - W], W = a multiple of the offset >= 256, so a
+          // trip only reads what earlier trips (or earlier groups) wrote; one dword per lane ----
+          acc_a++;
+          uint32_t W = run_off;
+          while (W < kGroup) W <<= 1;
+          cbar();
+          for (uint32_t x = g + kGroup + 4 * lane; x < run_end; x += kGroup) {
+            const uint32_t src = x - W;
+            const uint32_t lo32 = *reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
+            const uint32_t hi32 = *reinterpret_cast<const uint32_t*>(s_out + (src & ~3u) + 4);
+            *reinterpret_cast<uint32_t*>(s_out + x) = __funnelshift_r(lo32, hi32, (src & 3) * 8);
+          }
+          cbar();
+          nskip = 0;
+          for (;;) {
+            const uint32_t gg = run_end + kGroup * (nskip + lane);
+            const uint64_t sk = ballot(gg < cn && gg > cb && is_skip(gg));
+            const uint32_t c = (~sk) ? ctz64(~sk) : 64;
+            nskip += c;
+            if (c < 64) break;
+          }
+          front = run_end + kGroup * nskip;
+        } else {
+          front = g + kGroup * (1 + nskip);
+        }
         front = front < cn ? front : cn;
         cbar();
         if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
