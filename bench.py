@@ -42,6 +42,21 @@ HBM_PEAK_GBPS = 8000.0
 BLOCK = 65536
 
 
+def measured_traffic(nb, only):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_bench.sh
+    (FETCH_SIZE / WRITE_SIZE cannot be read inside this process: they need their own rocprofv3
+    passes).  The committed measurement is for the default workload only; anything else: None."""
+    if nb != 65536 or only is not None:
+        return None
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+    if not cands:
+        return None
+    with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
+        t = json.load(f)
+    k = t.get("kernels", {}).get("decode_indexed_kernel")
+    return None if k is None else k["total_bytes"]
+
+
 def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
     """Oracle (CPU port of the reference) on the first n_sample blocks, one thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -235,7 +250,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": None,
+                "traffic": measured_traffic(nb, args.only),
                 "kernel": "decode_indexed_kernel",
                 "kernel_ms": round(dec_ms, 4),
                 "index_pass_kernel_ms": round(idx_ms, 4),

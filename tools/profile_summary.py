@@ -1,0 +1,43 @@
+"""Condense the rocprofv3 outputs of tools/profile_bench.sh into one markdown summary."""
+import collections, csv, glob, json, os, sys
+out = sys.argv[1]
+def short(k):
+    for name in ("decode_indexed_kernel", "index_units_kernel", "decode_units_kernel", "encode_blocks_kernel",
+                 "crc32c_units_kernel", "gather_slots_kernel", "scan_sizes_kernel", "region_counts_kernel"):
+        if name in k:
+            return name
+    return k[:60]
+print("# rocprofv3 summary of `python3 bench.py` (1 x MI355X)\n")
+for f in ("bench.json", "bench_profiled.json"):
+    p = os.path.join(out, f)
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{"):
+                j = json.loads(line)
+                print("* `%s`: value %.1f %s, ms_per_step %.3f, roofline %s, compress %.2f GB/s" % (
+                    f, j["value"], j["unit"], j["ms_per_step"], json.dumps(j["roofline"]), j.get("compress_GBps", 0)))
+print("\n## kernel-trace --stats (bench.py --steps 5 --warmup 1 --no-cpu)\n")
+for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
+    print("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
+    for row in csv.DictReader(open(f)):
+        print("| %s | %s | %.3f | %.4f | %s |" % (short(row["Name"]), row["Calls"], float(row["TotalDurationNs"]) / 1e6,
+                                                 float(row["AverageNs"]) / 1e6, row["Percentage"]))
+print("\n## HBM traffic per launch (separate --pmc passes; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)\n")
+tr = collections.defaultdict(dict)
+for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    for f in glob.glob(out + "/" + d + "/*/*counter_collection.csv"):
+        acc = collections.defaultdict(float)
+        disp = collections.defaultdict(set)
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != name:
+                continue
+            k = short(row["Kernel_Name"])
+            acc[k] += float(row["Counter_Value"])
+            disp[k].add(row["Dispatch_Id"])
+        for k in acc:
+            tr[k][name] = acc[k] / max(1, len(disp[k])) * 1024.0  # KB -> bytes, mean per dispatch
+print("| kernel | read bytes (2 x FETCH_SIZE) | write bytes | total |\n|---|---|---|---|")
+for k, v in sorted(tr.items()):
+    rd = 2.0 * v.get("FETCH_SIZE", 0.0)
+    wr = v.get("WRITE_SIZE", 0.0)
+    print("| %s | %.4e | %.4e | %.4e |" % (k, rd, wr, rd + wr))
