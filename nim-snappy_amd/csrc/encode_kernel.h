@@ -16,7 +16,11 @@
 //   * the copy-loop probe at `ip` right after a copy (encoder.nim:371-380) rides along as lane 0
 //     of the next round, so one round finds either "copy again" or the next literal + copy;
 //   * match extension compares 256 bytes per step across the wave (ballot + ctz);
-//   * elements are emitted through a 4 KiB LDS staging buffer and flushed with wide stores.
+//   * elements are emitted through a 4 KiB LDS staging buffer and flushed with wide stores;
+//   * the bytes around the scan position live in a 2.3 KiB LDS window (refilled with 16-byte
+//     loads when the scan leaves it), so a round's only trip to HBM/L2 is the one that cannot be
+//     avoided: the candidates, which may lie anywhere earlier in the block.  A candidate is
+//     fetched 16 bytes wide, so matches of up to 16 bytes are measured from registers.
 //
 // The sixteen unrolled probes of encoder.nim:280-309 are the first sixteen steps of the same
 // sequence (skip 32..47 => step 1; the guard ipLimit >= ip+16 equals the per-probe guard
@@ -30,6 +34,7 @@ namespace snappy_hip {
 constexpr uint32_t kSeqLen = 320;  // probe-sequence entries (offset passes 65536 at ~250)
 constexpr uint32_t kObSize = 4096; // staging bytes
 constexpr uint32_t kObCap = kObSize + 3 * 64 + 16;
+constexpr uint32_t kWinSize = 2304;  // bytes of input around the scan position kept in LDS
 
 struct EncodeParams {
   const uint8_t* in;
@@ -52,8 +57,9 @@ __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
 __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize];
   __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
-  __shared__ uint32_t s_seq_off[kSeqLen];
-  __shared__ uint32_t s_seq_step[kSeqLen];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
+  __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
+  __shared__ uint16_t s_seq_step[kSeqLen];
 
   const uint32_t lane = lane_id();
   const uint64_t blk = blockIdx.x;
@@ -85,6 +91,26 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 
   uint32_t gpos = 0;   // body bytes already in HBM
   uint32_t ofill = 0;  // body bytes waiting in s_ob
+
+  // ---- input window: s_win[i] = in[wq - shift + i], wq a multiple of 16 in "q = p + shift" units --
+  const uint32_t shift = (uint32_t)((uintptr_t)in & 15);
+  const uint8_t* g0 = in - shift;
+  const uint32_t q_end = (shift + n + 15) & ~15u;
+  uint32_t wq = 0, wend = 0;  // window covers q in [wq, wend)
+  auto fill_window = [&](uint32_t p_first) {
+    wq = (p_first + shift) & ~15u;
+    wave_fence();
+    for (uint32_t i = lane; i < kWinSize / 16; i += 64) {
+      const uint32_t q = wq + 16 * i;
+      if (q < q_end) *reinterpret_cast<uint4*>(s_win + 16 * i) = *reinterpret_cast<const uint4*>(g0 + q);
+    }
+    wend = wq + kWinSize < q_end ? wq + kWinSize : q_end;
+    wave_fence();
+  };
+  auto in_window = [&](uint32_t p, uint32_t bytes) -> bool {
+    const uint32_t q = p + shift;
+    return q >= wq && (q + bytes <= wend || wend == q_end);  // (the block's end is always "inside")
+  };
 
   auto flush = [&]() {
     wave_fence();
@@ -121,7 +147,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
     }
     ofill += w;
-    if (len <= 1024) {
+    if (len <= 64 && in_window(from, len)) {  // the common case: straight from the window
+      if (lane < len) s_ob[ofill + lane] = s_win[from + shift - wq + lane];
+      ofill += len;
+    } else if (len <= 1024) {
       for (uint32_t i = lane * 4; i < len; i += 256) {
         if (i + 4 <= len) {
           st32u(s_ob + ofill + i, ld32u(in + from + i));
@@ -191,11 +220,18 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     for (uint32_t i = lane * 8; i < table_size; i += 64 * 8)
       *reinterpret_cast<uint4*>(&s_table[i]) = make_uint4(0, 0, 0, 0);
     for (uint32_t i = lane; i < kSeqLen; i += 64) {
-      s_seq_off[i] = prm.seq_off[i];
-      s_seq_step[i] = prm.seq_step[i];
+      const uint32_t o = prm.seq_off[i], st = prm.seq_step[i];
+      s_seq_off[i] = (uint16_t)(o < 65535 ? o : 65535);
+      s_seq_step[i] = (uint16_t)(st < 65535 ? st : 65535);
     }
+    // the first 64 entries (a fresh scan) stay in registers: [lane] and, for rounds whose lane 0
+    // carries the copy-loop probe, [lane - 1]
+    const uint32_t ra_off = prm.seq_off[lane], ra_step = prm.seq_step[lane];
+    const uint32_t rb_off = lane ? prm.seq_off[lane - 1] : 0, rb_step = lane ? prm.seq_step[lane - 1] : 0;
+    const uint32_t need0 = readlane(ra_off, 63) + 24;  // bytes after s0 a fresh scan may touch
     wave_fence();
     const uint32_t ip_limit = n - kInputMargin;
+    fill_window(0);
 
     bool has0 = false;        // lane 0 carries the copy-loop probe at s0-1
     uint32_t next_emit = 0;   // start of the pending literal
@@ -206,19 +242,44 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     for (;;) {
       // ---- this round's probe per lane ------------------------------------------------------
       const bool is0 = has0 && lane == 0;
-      const uint32_t si = idx0 + lane - (has0 ? 1u : 0u);
       uint32_t p = s0 - 1;
       bool valid = is0;
-      if (!is0 && si < kSeqLen) {
-        p = s0 + s_seq_off[si];
-        valid = p + s_seq_step[si] <= ip_limit;  // encoder.nim:318-321, before the table write
+      if (idx0 == 0) {  // a fresh scan: sequence in registers, bytes in the window
+        if (!in_window(s0 - 1, need0 + 1)) fill_window(s0 - 1);
+        const uint32_t off = has0 ? rb_off : ra_off, step = has0 ? rb_step : ra_step;
+        if (!is0) {
+          p = s0 + off;
+          valid = p + step <= ip_limit;  // encoder.nim:318-321, before the table write
+        }
+      } else {
+        const uint32_t si = idx0 + lane - (has0 ? 1u : 0u);
+        if (!is0 && si < kSeqLen) {
+          p = s0 + s_seq_off[si];
+          valid = p + s_seq_step[si] <= ip_limit;
+        }
       }
       const uint64_t vmask = ballot(valid);
       if (vmask == 0) {
         tail_from = next_emit;
         break;
       }
-      const uint32_t d = valid ? ld32u(in + p) : 0;
+      // 16 bytes at p (valid probes have p + 16 <= n): from the window when it holds them
+      const bool pw = valid && in_window(p, 20);
+      uint32_t pd[4] = {0, 0, 0, 0};
+      {
+        const uint32_t qa = pw ? (p + shift - wq) : 0;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+        const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
+        const uint32_t sh8 = (qa & 3) * 8;
+        pd[0] = __funnelshift_r(r0, r1, sh8);
+        pd[1] = __funnelshift_r(r1, r2, sh8);
+        pd[2] = __funnelshift_r(r2, r3, sh8);
+        pd[3] = __funnelshift_r(r3, r4, sh8);
+      }
+      if (ballot(valid && !pw)) {  // long scans run ahead of the window
+        if (valid && !pw) pd[0] = ld32u(in + p);
+      }
+      const uint32_t d = valid ? pd[0] : 0;
       const uint32_t h = snappy_hash(d, mask);
       const uint32_t old = valid ? s_table[h] : 0;
       wave_fence();
@@ -246,9 +307,21 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         losers &= ~g;
       }
 
-      const uint32_t cd = valid ? ld32u(in + cand) : ~d;
-      const uint64_t mm = ballot(valid && cd == d);
+      // the candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of
+      // encoder.nim:326 and, for window probes, the first 16 bytes of findMatchLength
+      uint4 cv = make_uint4(~d, 0, 0, 0);
+      if (valid) __builtin_memcpy(&cv, in + cand, 16);
+      const uint64_t mm = ballot(valid && cv.x == d);
       const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vmask);
+      uint32_t eq = 4;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
+      {
+        const uint32_t x1 = pd[1] ^ cv.y, x2 = pd[2] ^ cv.z, x3 = pd[3] ^ cv.w;
+        const uint32_t e3 = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : 16;
+        const uint32_t e2 = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : e3;
+        eq = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : e2;
+        // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
+        eq = eq < n - p ? eq : n - p;
+      }
 
       // ---- leave the table as the sequential loop would -------------------------------------
       if (mm) {
@@ -280,23 +353,25 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       const uint32_t c = readlane(cand, m_eff);
       if (pm > next_emit) emit_literal(next_emit, pm - next_emit);
 
-      uint32_t matched = 4;  // findMatchLength, encoder.nim:130-182: exact, bounded by n
-      {
-        uint32_t a = c + 4, b = pm + 4;
+      // findMatchLength, encoder.nim:130-182: exact, bounded by n
+      const bool wwide = readlane(pw ? 1u : 0u, m_eff) != 0;
+      uint32_t matched = wwide ? readlane(eq, m_eff) : 4;
+      if (!wwide || (matched == 16 && pm + 16 < n)) {  // longer (or not measured yet): 256 bytes per step
+        uint32_t a = c + matched, b = pm + matched;
         for (;;) {
           const uint32_t pb = b + lane * 4;
-          uint32_t eq = 0;
+          uint32_t e4 = 0;
           if (pb < n) {
             const uint32_t avail = n - pb < 4 ? n - pb : 4;
             const uint32_t sh = 4 - avail;  // keep the dword load inside the block
             uint32_t x = (ld32u(in + a + lane * 4 - sh) ^ ld32u(in + pb - sh)) >> (8 * sh);
-            eq = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4;
-            if (eq > avail) eq = avail;
+            e4 = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4;
+            if (e4 > avail) e4 = avail;
           }
-          const uint64_t mis = ballot(eq < 4);
+          const uint64_t mis = ballot(e4 < 4);
           if (mis) {
             const uint32_t f = ctz64(mis);
-            matched += 4 * f + readlane(eq, f);
+            matched += 4 * f + readlane(e4, f);
             break;
           }
           matched += 256;
@@ -311,7 +386,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         break;
       }
       // encoder.nim:371: table[hash(load32(ip-1))] = ip-1, before the probe at ip
-      if (lane == 0) s_table[snappy_hash(ld32u(in + ip - 1), mask)] = (uint16_t)(ip - 1);
+      if (!in_window(ip - 1, need0 + 2)) fill_window(ip - 1);  // (also what the next round needs)
+      if (lane == 0) {
+        const uint32_t qa = ip - 1 + shift - wq;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+        const uint32_t dd = __funnelshift_r(w32[0], w32[1], (qa & 3) * 8);
+        s_table[snappy_hash(dd, mask)] = (uint16_t)(ip - 1);
+      }
       wave_fence();
       has0 = true;
       s0 = ip + 1;

@@ -70,6 +70,22 @@ def test_every_small_length(hip, orc):
         assert hip.encode_frame(src) == orc.encode_frame(src), n
 
 
+def test_match_runs_into_block_end(hip, orc):
+    """findMatchLength is bounded by the block's end (encoder.nim:130-182), also when the copy-loop
+    probe sits exactly at ip = n - 15 (encoder.nim:362 lets it) and 15 bytes match to the end"""
+    rng = random.Random(7)
+    head = bytes(rng.randrange(256) for _ in range(300))
+    for tail in range(12, 40):
+        for gap in (0, 1, 3, 17):
+            # ... X[0:tail+20] ... filler ... X again, cut so that the block ends `tail` bytes into
+            # the second match region after an earlier copy
+            x = bytes(rng.randrange(256) for _ in range(tail + 24))
+            src = head + x + bytes(rng.randrange(256) for _ in range(50 + gap)) + x[:8] + b"#" + x[:tail]
+            assert hip.encode_block(src) == orc.encode_block(src), (tail, gap)
+            src2 = head + x + x[:20] + bytes([rng.randrange(256)]) * gap + x[:tail]
+            assert hip.encode_block(src2) == orc.encode_block(src2), (tail, gap)
+
+
 def test_random_strings(hip, orc):
     """tests/test_snappy.nim:247-253"""
     for s in bh.random_strings(0x5EED, count=40):
