@@ -48,6 +48,7 @@ struct EncodeParams {
   const uint32_t* crc;      // kUnitFrame: masked CRC32C per block (crc kernel ran first)
   const uint32_t* seq_off;  // probe sequence: offset of probe j from the scan start
   const uint32_t* seq_step; // ... and its step (skip >> 5)
+  unsigned long long* stats;  // DEBUG: per-section cycle counters (nullptr = off)
 };
 
 __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
@@ -55,7 +56,7 @@ __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
 }
 
 __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize];
+  __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
   __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
   __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
@@ -131,6 +132,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 
   // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
   auto emit_literal = [&](uint32_t from, uint32_t len) {
+    if (len <= 60 && in_window(from, len)) {  // the common case: one tag byte, payload from the window
+      reserve(61);
+      if (lane < len) s_ob[ofill + 1 + lane] = s_win[from + shift - wq + lane];
+      if (lane == 0) s_ob[ofill] = (uint8_t)((len - 1) << 2);
+      ofill += 1 + len;
+      return;
+    }
     const uint32_t m = len - 1;
     const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
     reserve(w + (len <= 1024 ? len : 0));
@@ -174,6 +182,22 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 
   // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
   auto emit_copy = [&](uint32_t offset, uint32_t length) {
+    if (length < 68) {  // the common case, branch-free: at most a 60-byte copy2 + one more element
+      reserve(8);
+      const bool two = length > 64;                      // :105-112
+      const uint32_t r = two ? length - 60 : length;     // 4..64
+      const bool c2 = r >= 12 || offset >= 2048;         // :114-125
+      const uint32_t lo = offset & 255, hi = offset >> 8;
+      const uint32_t last = c2 ? ((((r - 1) << 2) | 2) | (lo << 8) | (hi << 16))
+                               : (((hi << 5) | ((r - 4) << 2) | 1) | (lo << 8));
+      const uint32_t first = ((59u << 2) | 2) | (lo << 8) | (hi << 16);
+      const unsigned long long bytes = two ? ((unsigned long long)first | ((unsigned long long)last << 24))
+                                           : (unsigned long long)last;
+      const uint32_t total = (two ? 3 : 0) + (c2 ? 3 : 2);
+      if (lane < total) s_ob[ofill + lane] = (uint8_t)(bytes >> (8 * lane));
+      ofill += total;
+      return;
+    }
     uint32_t k64 = length >= 68 ? (length - 68) / 64 + 1 : 0;  // :97-103
     uint32_t rem = length - 64 * k64;                          // 4..67
     while (k64) {                                              // <= 64 elements per pass
@@ -224,50 +248,54 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       s_seq_off[i] = (uint16_t)(o < 65535 ? o : 65535);
       s_seq_step[i] = (uint16_t)(st < 65535 ? st : 65535);
     }
-    // the first 64 entries (a fresh scan) stay in registers: [lane] and, for rounds whose lane 0
-    // carries the copy-loop probe, [lane - 1]
+    // Lane roles of a round.  After a literal scan that found nothing yet (has0 = false) all 64
+    // lanes are scan probes: lane L probes s0 + off[idx0 + L].  Right after a copy that ended at
+    // ip (has0 = true) lane 0 is the table insert of ip - 1 (encoder.nim:371: a write that is
+    // never a match candidate check), lane 1 the copy-loop probe at ip (:373-380) and lanes 2..63
+    // are the first 62 probes of the scan that starts at ip + 1 -- the order of the lanes is the
+    // order in which the sequential loop touches the table.
+    // The first 64 sequence entries stay in registers in both arrangements (relative to s0 - 2
+    // for has0 rounds, to s0 otherwise); later entries come from LDS.
     const uint32_t ra_off = prm.seq_off[lane], ra_step = prm.seq_step[lane];
-    const uint32_t rb_off = lane ? prm.seq_off[lane - 1] : 0, rb_step = lane ? prm.seq_step[lane - 1] : 0;
-    const uint32_t need0 = readlane(ra_off, 63) + 24;  // bytes after s0 a fresh scan may touch
+    const uint32_t rb_off = lane >= 2 ? 2 + prm.seq_off[lane - 2] : lane;
+    const uint32_t rb_step = lane >= 2 ? prm.seq_step[lane - 2] : 0;
+    const uint32_t need0 = readlane(ra_off, 63) + 28;  // bytes after the first lane's position a fresh round may touch
     wave_fence();
     const uint32_t ip_limit = n - kInputMargin;
     fill_window(0);
 
-    bool has0 = false;        // lane 0 carries the copy-loop probe at s0-1
+    bool has0 = false;        // lanes 0,1 carry the insert of ip-1 and the copy-loop probe at ip = s0-1
     uint32_t next_emit = 0;   // start of the pending literal
     uint32_t s0 = 1;          // position of probe 0 of the current literal scan
     uint32_t idx0 = 0;        // index into the probe sequence of this round's first scan lane
     uint32_t tail_from = 0;   // where the final literal starts
 
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // DEBUG section timers
+    uint32_t rounds = 0;
+    auto tick = [&](int k) {
+      if (prm.stats) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        tacc[k] += t - tprev;
+        tprev = t;
+      }
+    };
+    if (prm.stats) tprev = __builtin_amdgcn_s_memtime();
     for (;;) {
-      // ---- this round's probe per lane ------------------------------------------------------
-      const bool is0 = has0 && lane == 0;
-      uint32_t p = s0 - 1;
-      bool valid = is0;
-      if (idx0 == 0) {  // a fresh scan: sequence in registers, bytes in the window
-        if (!in_window(s0 - 1, need0 + 1)) fill_window(s0 - 1);
-        const uint32_t off = has0 ? rb_off : ra_off, step = has0 ? rb_step : ra_step;
-        if (!is0) {
-          p = s0 + off;
-          valid = p + step <= ip_limit;  // encoder.nim:318-321, before the table write
-        }
-      } else {
-        const uint32_t si = idx0 + lane - (has0 ? 1u : 0u);
-        if (!is0 && si < kSeqLen) {
-          p = s0 + s_seq_off[si];
-          valid = p + s_seq_step[si] <= ip_limit;
-        }
-      }
-      const uint64_t vmask = ballot(valid);
-      if (vmask == 0) {
-        tail_from = next_emit;
-        break;
-      }
-      // 16 bytes at p (valid probes have p + 16 <= n): from the window when it holds them
-      const bool pw = valid && in_window(p, 20);
+      rounds++;
+      // ---- this round's position per lane, and 16 bytes of input there -------------------------
+      uint32_t p;
+      bool valid;
+      bool pw;  // the 16 bytes at p came from the window (else only pd[0] is loaded)
       uint32_t pd[4] = {0, 0, 0, 0};
-      {
-        const uint32_t qa = pw ? (p + shift - wq) : 0;
+      const uint32_t first_probe = has0 ? 1 : 0;  // lanes below it only write the table
+      if (idx0 == 0) {
+        // fresh round: everything it touches is in the window
+        const uint32_t base = has0 ? s0 - 2 : s0;
+        if (!in_window(base, need0)) fill_window(base);
+        p = base + (has0 ? rb_off : ra_off);
+        valid = p + (has0 ? rb_step : ra_step) <= ip_limit;  // encoder.nim:318-321 (lanes 0,1: step 0, ip <= ipLimit)
+        pw = valid;
+        const uint32_t qa = valid ? (p + shift - wq) : 0;
         const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
         const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
         const uint32_t sh8 = (qa & 3) * 8;
@@ -275,24 +303,42 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         pd[1] = __funnelshift_r(r1, r2, sh8);
         pd[2] = __funnelshift_r(r2, r3, sh8);
         pd[3] = __funnelshift_r(r3, r4, sh8);
+      } else {
+        // a long scan, far ahead of the window: straight from memory (never with has0)
+        const uint32_t si = idx0 + lane;
+        p = s0;
+        valid = false;
+        if (si < kSeqLen) {
+          p = s0 + s_seq_off[si];
+          valid = p + s_seq_step[si] <= ip_limit;
+        }
+        pw = false;
+        if (valid) pd[0] = ld32u(in + p);
       }
-      if (ballot(valid && !pw)) {  // long scans run ahead of the window
-        if (valid && !pw) pd[0] = ld32u(in + p);
+      const uint64_t vmask = ballot(valid);
+      if (vmask == 0) {
+        tail_from = next_emit;
+        break;
       }
-      const uint32_t d = valid ? pd[0] : 0;
+      const uint32_t d = pd[0];
+      tick(0);  // positions + input bytes
       const uint32_t h = snappy_hash(d, mask);
-      const uint32_t old = valid ? s_table[h] : 0;
+      // (a lane without a position works on its private sink slot instead of being branched around)
+      const uint32_t tsink = kMaxTableSize + lane;
+      const uint32_t ti = valid ? h : tsink;
+      const uint32_t old = s_table[ti];
       wave_fence();
-      if (valid) s_table[h] = (uint16_t)p;
+      s_table[ti] = (uint16_t)p;
       wave_fence();
-      const uint32_t chk = valid ? s_table[h] : p;
-      uint64_t losers = ballot(valid && chk != p);
+      const uint32_t chk = s_table[ti];
+      uint64_t losers = ballot(chk != (p & 0xffffu));
 
-      // candidate as the sequential loop would see it
+      // candidate as the sequential loop would see it: the position of the nearest earlier lane
+      // of this round with my slot, else what the table held
       uint32_t cand = old;
       uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
       const bool any_conflict = losers != 0;
-      while (losers) {
+      while (losers) {  // one pass per colliding slot
         const uint32_t j = ctz64(losers);
         const uint32_t hj = readlane(h, j);
         const uint64_t g = ballot(valid && h == hj);
@@ -306,12 +352,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         }
         losers &= ~g;
       }
+      tick(1);  // table read / write / read back, conflicts
 
       // the candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of
       // encoder.nim:326 and, for window probes, the first 16 bytes of findMatchLength
-      uint4 cv = make_uint4(~d, 0, 0, 0);
-      if (valid) __builtin_memcpy(&cv, in + cand, 16);
-      const uint64_t mm = ballot(valid && cv.x == d);
+      uint4 cv;
+      __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
+      const uint64_t mm = ballot(valid && lane >= first_probe && cv.x == d);
       const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vmask);
       uint32_t eq = 4;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
       {
@@ -322,11 +369,12 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
         eq = eq < n - p ? eq : n - p;
       }
+      tick(2);  // candidate fetch + compare
 
       // ---- leave the table as the sequential loop would -------------------------------------
       if (mm) {
         wave_fence();
-        if (valid && lane > m_eff) s_table[h] = (uint16_t)old;  // never executed there
+        s_table[(valid && lane > m_eff) ? h : tsink] = (uint16_t)old;  // never executed there
       }
       if (any_conflict) {
         wave_fence();
@@ -334,24 +382,26 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint64_t later = lane >= 63 ? 0 : (grp >> (lane + 1));
         const uint32_t span = m_eff > lane ? m_eff - lane : 0;  // lanes in (lane, m_eff]
         const uint64_t later_in = span >= 64 ? later : (later & ((1ull << span) - 1));
-        if (valid && lane <= m_eff && later_in == 0) s_table[h] = (uint16_t)p;
+        s_table[(valid && lane <= m_eff && later_in == 0) ? h : tsink] = (uint16_t)p;
       }
       wave_fence();
 
       if (!mm) {
-        if (vmask == ~0ull) {  // all 64 probes missed: next 64 of the sequence
-          idx0 += has0 ? 63 : 64;
+        if (vmask == ~0ull) {  // every probe missed: the next entries of the sequence
+          idx0 += has0 ? 62 : 64;
           has0 = false;
           continue;
         }
         tail_from = next_emit;  // encoder.nim:319-321
         break;
       }
+      tick(3);  // table repair
 
       // ---- literal + copy (encoder.nim:336-359) ---------------------------------------------
       const uint32_t pm = readlane(p, m_eff);
       const uint32_t c = readlane(cand, m_eff);
       if (pm > next_emit) emit_literal(next_emit, pm - next_emit);
+      tick(4);  // emit literal
 
       // findMatchLength, encoder.nim:130-182: exact, bounded by n
       const bool wwide = readlane(pw ? 1u : 0u, m_eff) != 0;
@@ -379,25 +429,23 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           b += 256;
         }
       }
+      tick(5);  // match length
       emit_copy(pm - c, matched);
+      tick(6);  // emit copy
       const uint32_t ip = pm + matched;
       if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
         tail_from = ip;
         break;
       }
-      // encoder.nim:371: table[hash(load32(ip-1))] = ip-1, before the probe at ip
-      if (!in_window(ip - 1, need0 + 2)) fill_window(ip - 1);  // (also what the next round needs)
-      if (lane == 0) {
-        const uint32_t qa = ip - 1 + shift - wq;
-        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
-        const uint32_t dd = __funnelshift_r(w32[0], w32[1], (qa & 3) * 8);
-        s_table[snappy_hash(dd, mask)] = (uint16_t)(ip - 1);
-      }
-      wave_fence();
+      // next round: insert of ip - 1 (:371), probe at ip (:373-380), scan from ip + 1
       has0 = true;
       s0 = ip + 1;
       idx0 = 0;
       next_emit = ip;
+    }
+    if (prm.stats && lane == 0) {
+      for (int k = 0; k < 8; k++) atomicAdd(&prm.stats[k], tacc[k]);
+      atomicAdd(&prm.stats[8], (unsigned long long)rounds);
     }
     if (tail_from < n) emit_literal(tail_from, n - tail_from);  // encoder.nim:249-253
   }

@@ -332,9 +332,25 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   p.crc = d_crc;
   p.seq_off = c->d_seq_off;
   p.seq_step = c->d_seq_step;
+  unsigned long long* d_estats = nullptr;
+  if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+    HIP_TRY(hipMalloc((void**)&d_estats, 128));
+    HIP_TRY(hipMemsetAsync(d_estats, 0, 128, s));
+    p.stats = d_estats;
+  }
   {
     LaunchTimer lt(c, s, 1);
     hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64), 0, s, p);
+  }
+  if (d_estats) {
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpyAsync(h, d_estats, 128, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double r = h[8] ? (double)h[8] : 1.0;
+    fprintf(stderr, "ENC STATS rounds/block %.0f; ticks per round: probe %.0f table %.0f cand %.0f repair %.0f "
+            "literal %.0f match %.0f copy %.0f insert %.0f\n", r / nb, h[0] / r, h[1] / r, h[2] / r, h[3] / r,
+            h[4] / r, h[5] / r, h[6] / r, h[7] / r);
+    (void)hipFree(d_estats);
   }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
