@@ -280,6 +280,17 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
     };
     if (prm.stats) tprev = __builtin_amdgcn_s_memtime();
+    // The elements of a round are written out during the NEXT round's wait for its candidates
+    // (the one access per round that goes to L2/HBM): emission only needs these four numbers.
+    bool pend = false;
+    uint32_t pend_from = 0, pend_pm = 0, pend_off = 0, pend_len = 0;
+    auto drain = [&]() {
+      if (pend) {
+        if (pend_pm > pend_from) emit_literal(pend_from, pend_pm - pend_from);
+        emit_copy(pend_off, pend_len);
+        pend = false;
+      }
+    };
     for (;;) {
       rounds++;
       // ---- this round's position per lane, and 16 bytes of input there -------------------------
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
       const uint64_t vmask = ballot(valid);
       if (vmask == 0) {
+        drain();
         tail_from = next_emit;
         break;
       }
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       // encoder.nim:326 and, for window probes, the first 16 bytes of findMatchLength
       uint4 cv;
       __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
+      drain();  // the previous round's literal + copy, while the candidates are in flight
       const uint64_t mm = ballot(valid && lane >= first_probe && cv.x == d);
       const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vmask);
       uint32_t eq = 4;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
@@ -400,8 +413,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       // ---- literal + copy (encoder.nim:336-359) ---------------------------------------------
       const uint32_t pm = readlane(p, m_eff);
       const uint32_t c = readlane(cand, m_eff);
-      if (pm > next_emit) emit_literal(next_emit, pm - next_emit);
-      tick(4);  // emit literal
+      tick(4);
 
       // findMatchLength, encoder.nim:130-182: exact, bounded by n
       const bool wwide = readlane(pw ? 1u : 0u, m_eff) != 0;
@@ -430,8 +442,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         }
       }
       tick(5);  // match length
-      emit_copy(pm - c, matched);
-      tick(6);  // emit copy
+      pend = true;  // literal input[next_emit ..< pm] + copy (pm - c, matched): emitted next round
+      pend_from = next_emit;
+      pend_pm = pm;
+      pend_off = pm - c;
+      pend_len = matched;
       const uint32_t ip = pm + matched;
       if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
         tail_from = ip;
@@ -443,6 +458,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       idx0 = 0;
       next_emit = ip;
     }
+    drain();
     if (prm.stats && lane == 0) {
       for (int k = 0; k < 8; k++) atomicAdd(&prm.stats[k], tacc[k]);
       atomicAdd(&prm.stats[8], (unsigned long long)rounds);
