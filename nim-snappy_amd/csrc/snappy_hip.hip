@@ -340,7 +340,8 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   }
   {
     LaunchTimer lt(c, s, 1);
-    hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
+                       getenv("SNAPPY_HIP_ENC_LDS") ? atoi(getenv("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
   }
   if (d_estats) {
     unsigned long long h[16];
