@@ -43,7 +43,8 @@ constexpr uint32_t kChunk = 64 * kRegion;           // stream bytes per wave ste
 constexpr uint32_t kRowStride = kRegion + 1;        // LDS row stride in dwords
 constexpr uint32_t kExitEnd = 0, kExitErr = 1;      // exit field: chain ended / invalid element
 constexpr uint32_t kExitFar = 992;                  // exit field >= 992: far exit, k = value-992
-constexpr uint32_t kOutSat = 0x1ffff;               // saturated output count (> 65536 = invalid)
+constexpr uint32_t kOutSat = 0x1ffff - 1024;        // saturated element length (> 65536 = invalid); leaves
+                                                    // room for the <= 16 x 64 bytes a region's chain adds on top
 constexpr uint32_t kIdxNone = 32;
 constexpr uint32_t kSub = 16;                       // stream bytes per index entry (half a region)
 constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's row in the size table
@@ -119,10 +120,40 @@ __device__ __forceinline__ bool decode_element(uint32_t tag, uint32_t b14, uint3
   return ok;
 }
 
+// The same without branches (selects only), for the pass that evaluates every byte position.
+__device__ __forceinline__ bool decode_element_bf(uint32_t tag, uint32_t b14, uint32_t rem, uint32_t* L,
+                                                  uint32_t* size) {
+  const uint32_t hi6 = tag >> 2, t = tag & 3;
+  // literal (decoder.nim:42-84)
+  const bool longlit = hi6 >= 60;
+  const uint32_t lenlen = longlit ? hi6 - 59 : 0;
+  const uint32_t m = 0xffffffffu >> (32 - 8 * (lenlen ? lenlen : 4));
+  const uint32_t llen = longlit ? (b14 & m) + 1 : hi6 + 1;
+  const uint32_t h = 1 + lenlen;
+  const bool lit_ok = (!longlit || (rem >= 61 && llen != 0)) && !(rem - (h - 1) < llen);  // :54-57, :67-68, :78
+  // copies (decoder.nim:86-109)
+  const uint32_t csize = t == 1 ? 2 : (t == 2 ? 3 : 5);
+  const bool copy_ok = rem >= csize - 1;
+  const uint32_t clen = t == 1 ? 4 + (hi6 & 7) : 1 + hi6;
+  *L = t == 0 ? llen : clen;
+  *size = t == 0 ? h + llen : csize;
+  return t == 0 ? lit_ok : copy_ok;
+}
+
 __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   __shared__ uint32_t s_tab[64 * kRowStride];
+  // per tag byte: element length [0:7), stream size [7:14), bit 14 = literal with length bytes
+  __shared__ uint16_t s_lut[256];
 
   const uint32_t lane = lane_id();
+  for (uint32_t tg = lane; tg < 256; tg += 64) {  // decoder.nim:42-109 for the forms without length bytes
+    const uint32_t hi6 = tg >> 2, ty = tg & 3;
+    const uint32_t len = ty == 1 ? 4 + (hi6 & 7) : 1 + hi6;          // literal < 61 and copy2/copy4: 1 + hi6
+    const uint32_t sz = ty == 0 ? 1 + len : (ty == 1 ? 2 : (ty == 2 ? 3 : 5));
+    const bool longlit = ty == 0 && hi6 >= 60;
+    s_lut[tg] = (uint16_t)(longlit ? (1u << 14) : (len | (sz << 7)));
+  }
+  wave_fence();
   const uint64_t u = blockIdx.x;
   if (u >= prm.n_units) return;
   const uint8_t* in0 = prm.in + prm.in_off[u];
@@ -212,41 +243,40 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
 #pragma unroll
       for (int k = kRegion - 1; k >= 0; k--) {
         const uint32_t p = rs + k;
-        uint32_t t;
-        uint32_t szb = 255;
-        if (p >= n) {
-          t = t_pack(kExitEnd, 0, 0);
-        } else {
-          const uint32_t lo = w[k >> 2], hi = w[(k >> 2) + 1], hi2 = w[(k >> 2) + 2];
-          const uint32_t sh8 = (k & 3) * 8;
-          const uint32_t d0 = sh8 ? __funnelshift_r(lo, hi, sh8) : lo;   // bytes k..k+3
-          const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
-          const uint32_t tag = d0 & 0xff;
-          const uint32_t b14 = (d0 >> 8) | (d1 << 24);
-          const uint32_t rem = n - p - 1;
-          bool is_copy;
-          uint32_t L, size, hdr, off;
-          const bool ok = decode_element(tag, b14, rem, &is_copy, &L, &size, &hdr, &off);
-          const uint32_t Ls = L < kOutSat ? L : kOutSat;
-          if (!ok) {
-            t = t_pack(kExitErr, 0, 0);
-          } else {
-            szb = size < 255 ? size : 255;
-            const uint32_t nx = (uint32_t)k + size;  // ok => size <= rem + 1: no wrap
-            if (nx >= kRegion) {
-              t = t_pack(nx < kExitFar ? nx : kExitFar + (uint32_t)k, 1, Ls);
-            } else {
-              const uint32_t tn = s_tab[row + nx];
-              if (t_exit(tn) == kExitErr) {
-                t = tn;
-              } else {
-                uint32_t o = Ls + t_out(tn);
-                if (o > kOutSat) o = kOutSat;
-                t = t_pack(t_exit(tn), t_nelem(tn) + 1, o);
-              }
-            }
-          }
+        // (selects only: a divergent branch per position costs more than the work it skips)
+        const uint32_t lo = w[k >> 2], hi = w[(k >> 2) + 1], hi2 = w[(k >> 2) + 2];
+        const uint32_t sh8 = (k & 3) * 8;
+        const uint32_t d0 = sh8 ? __funnelshift_r(lo, hi, sh8) : lo;   // bytes k..k+3
+        const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
+        const uint32_t tag = d0 & 0xff;
+        const uint32_t b14 = (d0 >> 8) | (d1 << 24);
+        const bool inside = p < n;
+        const uint32_t e = s_lut[tag];
+        uint32_t L = e & 127, size = (e >> 7) & 127;
+        bool ok = inside && p + size <= n;  // every short form: the element must end inside the stream
+        if (ballot(inside && (e >> 14))) {  // a literal with length bytes somewhere (rare in text)
+          const uint32_t rem = inside ? n - p - 1 : 0;
+          const uint32_t lenlen = (tag >> 2) - 59;  // 1..4 where it applies
+          const uint32_t m = 0xffffffffu >> (32 - 8 * (lenlen & 7 ? (lenlen & 7) : 4));
+          const uint32_t llen = (b14 & m) + 1;
+          const bool lok = rem >= 61 && llen != 0 && !(rem - lenlen < llen);  // decoder.nim:54-57, :67-68, :78
+          const bool ll = inside && (e >> 14);
+          L = ll ? llen : L;
+          size = ll ? 1 + lenlen + llen : size;
+          ok = ll ? lok : ok;
         }
+        const uint32_t Ls = L < kOutSat ? L : kOutSat;
+        const uint32_t nx = (uint32_t)k + size;  // ok => no wrap
+        const bool inreg = ok && nx < kRegion;
+        const uint32_t tn = s_tab[row + (inreg ? nx : (uint32_t)k)];
+        // the fields are additive along the chain: same exit, one more element, L more bytes
+        // (an error or end entry keeps its exit code; in-region lengths are <= 64, so the 17-bit
+        // sum cannot overflow past the saturated terminal element)
+        const uint32_t t_in = tn + ((1u << 10) | (L << 15));
+        const uint32_t t_out_of = (nx < kExitFar ? nx : kExitFar + (uint32_t)k) | (1u << 10) | (Ls << 15);
+        const uint32_t t = !inside ? t_pack(kExitEnd, 0, 0)
+                                   : (!ok ? t_pack(kExitErr, 0, 0) : (inreg ? t_in : t_out_of));
+        const uint32_t szb = ok ? (size < 255 ? size : 255) : 255;
         s_tab[row + k] = t;
         s_sz[row8 + k] = (uint8_t)szb;
       }
