@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       uint32_t front = cb;  // what I know of s_front
       for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn; g += kD2Pool * kGroup) {
         const uint32_t ge = g > cb ? readfirst((uint32_t)s_gidx[g / kGroup]) : 0;
-        if (g > cb && readfirst(is_skip(g) ? 1u : 0u)) continue;
+        if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
         const uint32_t p = g + 4 * lane;
         front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -362,9 +362,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const uint32_t wbits = r32[lane >> 3];
         cbar();
         // my bytes that belong to this step: [lo, hi) of 0..4
-        const uint32_t lo = p >= cb ? 0 : (cb - p < 4 ? cb - p : 4);
-        const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
-        const uint32_t rmask = ((1u << hi) - 1) & ~((1u << lo) - 1);
+        uint32_t rmask = 15;
+        if (g < cb || g + kGroup > cn) {  // only the step's first and last group are partial
+          const uint32_t lo = p >= cb ? 0 : (cb - p < 4 ? cb - p : 4);
+          const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
+          rmask = ((1u << hi) - 1) & ~((1u << lo) - 1);
+        }
         const uint32_t cbits = (wbits >> ((4 * lane) & 31)) & rmask;
         uint32_t tot;
         const uint32_t excl = wave_excl_scan((uint32_t)__builtin_popcount(cbits), lane, &tot);
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
               ((uint32_t)s_out[sp[3]] << 24);
         // how many of the groups after mine are skipped: I publish them with mine
         uint32_t nskip = 0;
-        for (;;) {
+        // (only looked into when the next group starts inside a long literal)
+        while (g + kGroup < cn && (readfirst((uint32_t)s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)]) & 0x8000u)) {
           const uint32_t gg = g + kGroup * (1 + nskip + lane);
           const uint64_t sk = ballot(gg < cn && is_skip(gg));
           const uint32_t c = (~sk) ? ctz64(~sk) : 64;
