@@ -88,6 +88,25 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         passes += 1
         assert st == 0
     assert np.array_equal(dec, src)
+    # the same sample, block ranges spread over all host threads (SURVEY 8d "B2"; ctypes releases the GIL)
+    import concurrent.futures as cf
+    nthr = min(os.cpu_count() or 1, 64, n_sample)
+    per = (n_sample + nthr - 1) // nthr
+
+    def part(k):
+        lo, hi = k * per, min(n_sample, (k + 1) * per)
+        if lo >= hi:
+            return 0
+        return orc.lib.sor_uncompress_blocks(out.ctypes.data, offs[lo:].ctypes.data, csz[lo:].ctypes.data,
+                                             hi - lo, dec.ctypes.data + lo * BLOCK, BLOCK)
+
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(part, range(nthr)))  # warm
+        t0 = time.perf_counter()
+        mt_passes = 4
+        for _ in range(mt_passes):
+            assert all(r == 0 for r in ex.map(part, range(nthr)))
+        t_mt = time.perf_counter() - t0
     return {
         "value": round(n_sample * BLOCK * passes / t_dec / 1e9, 4),
         "unit": "GB/s uncompressed (decompress)",
@@ -96,6 +115,8 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         "sample": "first %d blocks (%d MiB) of the same corpus, %d decode passes; "
                   "oracle/snappy_oracle.c -O3, one thread" % (n_sample, n_sample // 16, passes),
         "compress_value": round(n_sample * BLOCK / t_enc / 1e9, 4),
+        "threads": nthr,
+        "threads_value": round(n_sample * BLOCK * mt_passes / t_mt / 1e9, 3),
         "host_cpus": os.cpu_count(),
     }
 
@@ -218,6 +239,16 @@ def main():
     ctx.sync()
     t_fdec = time.perf_counter() - t0
 
+    # ---- measured copy bandwidth of this box: the second roofline denominator of SURVEY 8(d) -------
+    torch.cuda.synchronize()
+    d_out.copy_(d_in)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        d_out.copy_(d_in)
+    torch.cuda.synchronize()
+    copy_gbps = 3 * 2 * nb * BLOCK / (time.perf_counter() - t0) / 1e9
+
     if rank == 0:
         u_bytes = nb * BLOCK
         value = world * u_bytes * args.steps / elapsed / 1e9
@@ -250,6 +281,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "measured_copy_GBps": round(copy_gbps, 1),  # device-to-device copy, read + write
+                "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "traffic": measured_traffic(nb, args.only),
                 "kernel": "decode_indexed_kernel",
                 "kernel_ms": round(dec_ms, 4),
