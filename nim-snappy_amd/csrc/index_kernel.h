@@ -75,6 +75,7 @@ struct IndexParams {
   uint32_t* idx;
   uint64_t n_units;
   int unit;
+  uint32_t* blk_in;  // split mode: stream position (after the varint) where output block k starts
 };
 
 // Decode "the element that would start here" from its tag and the four bytes after it.
@@ -140,6 +141,13 @@ __device__ __forceinline__ bool decode_element_bf(uint32_t tag, uint32_t b14, ui
   return t == 0 ? lit_ok : copy_ok;
 }
 
+// SPLIT = false: the index pass of the block decoder (units of at most 64 KiB output).
+// SPLIT = true: one wave walks ONE raw buffer of any length the same way, chunk after chunk, and
+// records where every 64 KiB block of its output starts in the stream, so that the blocks can
+// then be decoded in parallel like independent units.  That works when no element straddles a
+// 64 KiB output boundary (true for every encoder that works in 64 KiB blocks, snappy.nim:49-62);
+// otherwise the unit is handed to the whole-stream kernel (kNeedsStreamKernel).
+template <bool SPLIT>
 __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   __shared__ uint32_t s_tab[64 * kRowStride];
   // per tag byte: element length [0:7), stream size [7:14), bit 14 = literal with length bytes
@@ -188,12 +196,13 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
     if (cap == 0) return finish(kBufferTooSmall, 0);
     limit = cap;
   }
-  if (exact && limit > kMaxBlockLen) return finish(kNeedsStreamKernel, 0);
-  const uint32_t win_limit = limit < kMaxBlockLen ? limit : kMaxBlockLen;
+  if (!SPLIT && exact && limit > kMaxBlockLen) return finish(kNeedsStreamKernel, 0);
+  const uint32_t win_limit = SPLIT ? limit : (limit < kMaxBlockLen ? limit : kMaxBlockLen);
   // what an over-long output means: a bigger unit goes to the whole-stream kernel
   const uint32_t too_long = limit > win_limit ? kNeedsStreamKernel : kInvalidInput;
 
-  if (n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // positions below fit 32 bits
+  if (!SPLIT && n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // (SPLIT: the host bounds n and the length)
+  bool straddle = false;  // SPLIT: an element crosses a 64 KiB output boundary
 
   __shared__ uint8_t s_sz[64 * kSizeStride];  // stream size of the element at each position
 
@@ -333,9 +342,36 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
     uint32_t tot;
     const uint32_t before = wave_excl_scan(out_here, lane, &tot);
     if (op + tot > win_limit) return finish(too_long, 0);
+    // SPLIT: a saturated length (an element of more than ~127 KiB) cannot be placed: whole-stream kernel
+    if (SPLIT && ballot(out_here >= kOutSat)) return finish(kNeedsStreamKernel, 0);
 
-    // ---- split my entry at the 16-byte boundary -------------------------------------------------
     const uint32_t pos0 = op + before;
+    if (SPLIT) {
+      // ---- a 64 KiB output boundary inside my region's elements: which element starts there? ------
+      const uint32_t kb = (pos0 + kMaxBlockLen - 1) / kMaxBlockLen;  // first boundary at or after pos0
+      const uint32_t B = kb * kMaxBlockLen;
+      if (entry_off != kIdxNone && kb >= 1 && B - pos0 < out_here) {
+        uint32_t pw = entry_off, dst = pos0;
+        bool found = false;
+        for (uint32_t it = 0; it < kRegion && pw < kRegion; it++) {
+          if (dst >= B) break;
+          const uint32_t sz = s_sz[row8 + pw];
+          const uint32_t nx = pw + sz;
+          const uint32_t rest = t_out(s_tab[row + pw]);                       // bytes from pw to the exit
+          const uint32_t after = nx < kRegion ? t_out(s_tab[row + nx]) : 0;  // ... from the next element
+          dst += rest - after;
+          pw = nx;
+        }
+        found = dst == B && pw < kRegion && rs + pw < n;
+        if (found) prm.blk_in[kb] = rs + pw;
+        // not at an element start, or the region's last element runs over the next boundary too
+        if (!found && dst != B) straddle = true;
+        // (dst == B without an element here: the chain left my region exactly at the boundary, the
+        // region it lands in records it)
+        if (pos0 + out_here > B + kMaxBlockLen) straddle = true;
+      }
+    } else {
+    // ---- split my entry at the 16-byte boundary -------------------------------------------------
     uint32_t e0 = kIdxNone, e1 = kIdxNone, nc0 = 0, nc1 = 0, pos1 = pos0 + out_here;
     {
       uint32_t pw = entry_off;  // walk to the first element at or after byte 16 (none = 32)
@@ -360,12 +396,14 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
       idx[2 * (rs / kRegion)] = e0 | (nc0 << 6) | (pos0 << 11);
       idx[2 * (rs / kRegion) + 1] = e1 | (nc1 << 6) | (pos1 << 11);
     }
+    }
     op += tot;
   }
 
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
+  if (SPLIT && ballot(straddle)) return finish(kNeedsStreamKernel, 0);
   finish(kOk, op);
 }
 

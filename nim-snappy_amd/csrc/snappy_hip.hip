@@ -449,7 +449,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     }
     {
       LaunchTimer lt(c, s, 4);
-      hipLaunchKernelGGL(index_units_kernel, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+      hipLaunchKernelGGL(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
     }
     if (getenv("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
       uint32_t* d_rep;
@@ -696,6 +696,86 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   return SNAPPY_HIP_OK;
 }
 
+// uncompress() of a raw buffer that decodes to more than one 64 KiB block.  The stream has no block
+// delimiters (snappy.nim:49-62), so one wave first walks it and records where every 64 KiB of
+// output starts (index_units_kernel<true>); the blocks are then decoded in parallel like
+// independent units.  Returns -1 when that does not apply (an element or a copy crosses a 64 KiB
+// output boundary, possible with foreign encoders): the caller then uses the serial kernel.
+int uncompress_split_host(const uint8_t* in, size_t n, uint32_t hdr, uint64_t len, uint8_t* out,
+                          size_t* written) {
+  if (len > (1ull << 31) || n > (1ull << 31)) return -1;
+  snappy_hip_ctx* c;
+  int st = default_ctx(&c);
+  if (st) return st;
+  const size_t nblk = (size_t)((len + kMaxBlockLen - 1) / kMaxBlockLen);
+  void *d_in, *d_out, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_blk, *d_one;
+  if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
+  if ((st = ws_get(c, 4, len + 64, &d_out))) return st;
+  if ((st = ws_get(c, 3, nblk * 8, &d_io))) return st;
+  if ((st = ws_get(c, 2, nblk * 4, &d_il))) return st;
+  if ((st = ws_get(c, 5, nblk * 8, &d_oo))) return st;
+  if ((st = ws_get(c, 6, nblk * 4, &d_oc))) return st;
+  if ((st = ws_get(c, 7, nblk * 4, &d_ol))) return st;
+  if ((st = ws_get(c, 8, nblk * 4, &d_st))) return st;
+  if ((st = ws_get(c, 9, (nblk + 1) * 4, &d_blk))) return st;
+  if ((st = ws_get(c, 10, 64, &d_one))) return st;
+  hipStream_t s = c->stream;
+  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+  // the splitter's one unit: [in_off u64 | in_len u32 | out_cap u32 | out_len u32 | status u32]
+  struct {
+    uint64_t in_off;
+    uint32_t in_len, out_cap, out_len, status;
+  } one = {0, (uint32_t)n, (uint32_t)len, 0, 0};
+  HIP_TRY(hipMemcpyAsync(d_one, &one, sizeof(one), hipMemcpyHostToDevice, s));
+  IndexParams ip{};
+  ip.in = (const uint8_t*)d_in;
+  ip.in_off = (const uint64_t*)d_one;
+  ip.in_len = (const uint32_t*)((uint8_t*)d_one + 8);
+  ip.out_cap = (const uint32_t*)((uint8_t*)d_one + 12);
+  ip.out_len = (uint32_t*)((uint8_t*)d_one + 16);
+  ip.status = (uint32_t*)((uint8_t*)d_one + 20);
+  ip.n_units = 1;
+  ip.unit = kUnitRaw;
+  ip.blk_in = (uint32_t*)d_blk;
+  hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64), 0, s, ip);
+  std::vector<uint32_t> blk(nblk + 1);
+  HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(blk.data(), d_blk, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
+  if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
+  blk[0] = 0;
+  blk[nblk] = (uint32_t)(n - hdr);
+  std::vector<uint64_t> io(nblk), oo(nblk);
+  std::vector<uint32_t> il(nblk), oc(nblk);
+  for (size_t k = 0; k < nblk; k++) {
+    if (blk[k] == 0xffffffffu || blk[k + 1] == 0xffffffffu || blk[k + 1] < blk[k]) return -1;
+    io[k] = hdr + (uint64_t)blk[k];
+    il[k] = blk[k + 1] - blk[k];
+    oo[k] = (uint64_t)k * kMaxBlockLen;
+    oc[k] = (uint32_t)(len - oo[k] < kMaxBlockLen ? len - oo[k] : kMaxBlockLen);
+  }
+  HIP_TRY(hipMemcpyAsync(d_io, io.data(), nblk * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_il, il.data(), nblk * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_oo, oo.data(), nblk * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_oc, oc.data(), nblk * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
+  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nblk,
+                     (int)kUnitBody, nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
+                     (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+    return st;
+  std::vector<uint32_t> stv(nblk), olv(nblk);
+  HIP_TRY(hipMemcpyAsync(stv.data(), d_st, nblk * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(olv.data(), d_ol, nblk * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (size_t k = 0; k < nblk; k++)
+    if (stv[k] != kOk || olv[k] != oc[k]) return -1;  // e.g. a copy that reaches into an earlier block
+  HIP_TRY(hipMemcpy(out, d_out, len, hipMemcpyDeviceToHost));
+  *written = (size_t)len;
+  return SNAPPY_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
@@ -808,6 +888,10 @@ extern "C" int snappy_hip_uncompress(const uint8_t* in, size_t n, uint8_t* out, 
   if ((uint64_t)cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
   if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;       // unit lengths are 32-bit
   std::lock_guard<std::mutex> lk(g_mu);
+  if (len > kMaxBlockLen && !getenv("SNAPPY_HIP_NO_SPLIT")) {  // several blocks: split, then decode in parallel
+    const int rs = uncompress_split_host(in, n, (uint32_t)hdr, len, out, written);
+    if (rs >= 0) return rs;
+  }
   // the kernel re-parses the header: one RAW unit, output window = the declared length
   std::vector<HostUnit> units{{0, (uint32_t)n, 0, (uint32_t)len, (uint8_t)kUnitRaw}};
   std::vector<uint32_t> st, ol, crc;

@@ -86,6 +86,48 @@ def test_match_runs_into_block_end(hip, orc):
             assert hip.encode_block(src2) == orc.encode_block(src2), (tail, gap)
 
 
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _literal(data):
+    n = len(data) - 1
+    if n < 60:
+        return bytes([n << 2]) + data
+    ll = (n.bit_length() + 7) // 8
+    return bytes([(59 + ll) << 2]) + n.to_bytes(ll, "little") + data
+
+
+def test_raw_multi_block_streams(hip, orc):
+    """uncompress() of raw buffers that decode to several 64 KiB blocks: streams of a 64 KiB-block
+    encoder are split and decoded in parallel; foreign streams whose elements or copies cross a
+    64 KiB output boundary must give the same bytes through the serial path (decoder.nim:20-155
+    works on the whole buffer, snappy.nim:92-110)"""
+    rng = random.Random(11)
+    text = golden_file("alice29.txt") + golden_file("html")
+    # 1. from the encoder itself (elements never cross a block boundary)
+    for n in (65537, 131072, 200000, len(text)):
+        comp = orc.encode(text[:n])
+        assert hip.decode(comp) == text[:n]
+    # 2. a literal that straddles the boundary
+    a = bytes(rng.randrange(256) for _ in range(70000))
+    b = bytes(rng.randrange(256) for _ in range(3000))
+    s2 = _varint(len(a) + len(b) + 64) + _literal(a) + _literal(b) + bytes([(63 << 2) | 2, 0x10, 0x00])
+    assert hip.decode(s2) == orc.decode(s2) != b""
+    # 3. block-aligned elements, but a copy in the second block that reads from the first one
+    c = bytes(rng.randrange(256) for _ in range(65536))
+    s3 = _varint(65536 + 64 + 100) + _literal(c) + bytes([(63 << 2) | 2, 0xff, 0xff]) + _literal(b[:100])
+    assert hip.decode(s3) == orc.decode(s3) != b""
+    # 4. the same kinds, damaged: identical verdicts
+    for bad in (orc.encode(text[:200000])[:-3], s2[:-1], s3[:40000], s3[:-101] + bytes([0xfc])):
+        assert hip.uncompress(bad, 400000)[0] == orc.uncompress(bad, 400000)[0] != bh.OK
+
+
 def test_random_strings(hip, orc):
     """tests/test_snappy.nim:247-253"""
     for s in bh.random_strings(0x5EED, count=40):
