@@ -226,3 +226,63 @@ def test_mutation_fuzz_matches_oracle(hip, orc):
                 assert hip.decode(m) == b""
                 continue
             assert hip.uncompress(m, n) == orc.uncompress(m, n)
+
+
+def _random_stream(rng, target, far=False):
+    """A valid tag stream built element by element: every tag form the decoder knows
+    (decoder.nim:42-109), including the ones the reference's encoder never emits -- literals
+    with 3 and 4 length bytes, copy4, copy2 of length 1..3, self-overlapping copies."""
+    out = bytearray()
+    body = bytearray()
+    while len(out) < target:
+        kind = rng.random()
+        if kind < 0.3 or len(out) == 0:
+            n = rng.choice([1, 2, 3, 5, 17, 59, 60, 61, 70, 255, 256, 257, 300, 2000])
+            data = rng.randbytes(n)
+            form = rng.random()
+            m = n - 1
+            if m < 60:
+                body += bytes([m << 2])
+            else:  # (length bytes need >= 61 stream bytes after the tag, decoder.nim:54-57: n >= 61 here)
+                ll = max((m.bit_length() + 7) // 8, 1)
+                ll = min(4, ll + (1 if form > 0.8 else 0))  # non-minimal length bytes too
+                body += bytes([(59 + ll) << 2]) + m.to_bytes(ll, "little")
+            body += data
+            out += data
+        else:
+            off = rng.randint(1, min(len(out), 65535 if not far else len(out)))
+            if rng.random() < 0.3:
+                off = rng.randint(1, min(len(out), 12))  # short offsets: overlapping copies
+            form = rng.random()
+            if form < 0.4 and off < 2048:
+                ln = rng.randint(4, 11)
+                body += bytes([((off >> 8) << 5) | ((ln - 4) << 2) | 1, off & 0xff])
+            elif form < 0.9 and off < 65536:
+                ln = rng.randint(1, 64)
+                body += bytes([((ln - 1) << 2) | 2]) + off.to_bytes(2, "little")
+            else:
+                ln = rng.randint(1, 64)
+                body += bytes([((ln - 1) << 2) | 3]) + off.to_bytes(4, "little")
+            for _ in range(ln):
+                out.append(out[-off])
+    return bytes(body), bytes(out)
+
+
+def test_random_valid_streams_match_oracle(hip, orc):
+    """streams of a foreign encoder: all element forms, through the block path (<= 64 KiB) and the
+    raw multi-block path"""
+    rng = random.Random(2024)
+    for i in range(60):
+        target = rng.choice([50, 700, 5000, 30000, 65000])
+        body, plain = _random_stream(rng, target)
+        if len(plain) > 65536:
+            continue
+        assert orc.decode_all_tags(body, len(plain)) == (0, plain)
+        assert hip.decode_all_tags(body, len(plain)) == (0, plain), i
+        raw = _varint(len(plain)) + body
+        assert hip.decode(raw) == plain, i
+    for i in range(6):  # several blocks, elements placed without regard to 64 KiB boundaries
+        body, plain = _random_stream(rng, rng.choice([70000, 150000, 300000]), far=True)
+        raw = _varint(len(plain)) + body
+        assert orc.decode(raw) == plain
+        assert hip.decode(raw) == plain, i
