@@ -147,9 +147,15 @@ __device__ __forceinline__ bool decode_element_bf(uint32_t tag, uint32_t b14, ui
 // then be decoded in parallel like independent units.  That works when no element straddles a
 // 64 KiB output boundary (true for every encoder that works in 64 KiB blocks, snappy.nim:49-62);
 // otherwise the unit is handed to the whole-stream kernel (kNeedsStreamKernel).
+// In SPLIT mode kSplitWaves waves share the walk: the tables of a chunk do not depend on where the
+// element chain enters it, so wave w prepares chunks w, w+4, ... ahead of time and only the short
+// chain step waits for the previous chunk's result (handed on through an LDS mailbox).
+constexpr uint32_t kSplitWaves = 4;
 template <bool SPLIT>
-__global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
-  __shared__ uint32_t s_tab[64 * kRowStride];
+__global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_kernel(IndexParams prm) {
+  constexpr uint32_t W = SPLIT ? kSplitWaves : 1;
+  __shared__ uint32_t s_tab[W * 64 * kRowStride];
+  __shared__ uint32_t s_mail[8][4];  // SPLIT: [chunk & 7] = {chunk + 1, entry_abs, op, state | straddle << 2}
   // per tag byte: element length [0:7), stream size [7:14), bit 14 = literal with length bytes
   __shared__ uint16_t s_lut[256];
 
@@ -161,7 +167,13 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
     const bool longlit = ty == 0 && hi6 >= 60;
     s_lut[tg] = (uint16_t)(longlit ? (1u << 14) : (len | (sz << 7)));
   }
-  wave_fence();
+  const uint32_t wave = SPLIT ? readfirst(threadIdx.x >> 6) : 0;
+  if (SPLIT) {
+    if (threadIdx.x < 32) (&s_mail[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+  } else {
+    wave_fence();
+  }
   const uint64_t u = blockIdx.x;
   if (u >= prm.n_units) return;
   const uint8_t* in0 = prm.in + prm.in_off[u];
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   if (!SPLIT && n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // (SPLIT: the host bounds n and the length)
   bool straddle = false;  // SPLIT: an element crosses a 64 KiB output boundary
 
-  __shared__ uint8_t s_sz[64 * kSizeStride];  // stream size of the element at each position
+  __shared__ uint8_t s_sz[W * 64 * kSizeStride];  // stream size of the element at each position
 
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
   const uint8_t* g0 = in0 - shift;                // 16-byte aligned
@@ -213,14 +225,39 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
   uint32_t entry_abs = 0;  // stream position of the next real element (uniform)
   uint32_t op = 0;         // output bytes before it (uniform)
   bool ended = false;
-  const uint32_t row = lane * kRowStride;
-  const uint32_t row8 = lane * kSizeStride;
+  const uint32_t row = (wave * 64 + lane) * kRowStride;
+  const uint32_t row8 = (wave * 64 + lane) * kSizeStride;
 
-  for (uint32_t c0 = 0; c0 < n && !ended; c0 += kChunk) {
+  // SPLIT: hand the chain over to the wave that owns the next chunk / tell everybody to stop
+  auto post = [&](uint32_t ci, uint32_t state, uint32_t e_abs, uint32_t o, bool strad) {
+    if (lane == 0) {
+      uint32_t* m = s_mail[ci & 7];
+      m[1] = e_abs;
+      m[2] = o;
+      m[3] = state | (strad ? 4u : 0u);
+      asm volatile("" ::: "memory");
+      __hip_atomic_store(&m[0], ci + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  bool strad_before = false;  // SPLIT: a straddling element in an earlier chunk
+  unsigned long long tA = 0, tW = 0, tC = 0, tt0 = 0, tt1 = 0, tt2 = 0;  // DEBUG (SPLIT, prm.idx != nullptr)
+  const bool dbgt = SPLIT && prm.idx != nullptr;
+  if (SPLIT && wave == 0) post(0, 0, 0, 0, false);
+
+  for (uint32_t c0 = wave * kChunk; c0 < n && !ended; c0 += W * kChunk) {
     const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position
+    const uint32_t ci = c0 / kChunk;
     uint32_t entry_off = kIdxNone, out_here = 0, nelem_here = 0;
+    // a verdict inside the loop: write it and, in SPLIT mode, stop the other waves
+    auto bail = [&](uint32_t st) {
+      finish(st, 0);
+      if (SPLIT) post(ci + 1, 2, 0, 0, false);
+    };
 
-    if (entry_abs < c0 + kChunk) {  // otherwise a long literal covers the whole chunk
+    if (dbgt) tt0 = __builtin_amdgcn_s_memtime();
+    // (the tables of a chunk that a long literal covers entirely are not needed; SPLIT cannot
+    // know that yet and builds them anyway)
+    if (SPLIT || entry_abs < c0 + kChunk) {
       // ---- my 32 region bytes + 8 bytes lookahead, from 16-byte aligned loads ---------------
       uint32_t w[10];
       {
@@ -290,14 +327,16 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
         s_sz[row8 + k] = (uint8_t)szb;
       }
       wave_fence();
-
-      // ---- chain across the regions: fixed point ------------------------------------------------
-      // in_abs = stream position at which the element chain arrives at my region (>= rs)
-      uint32_t in_abs = lane == 0 ? entry_abs : rs;
-      uint32_t out_abs;
-      uint32_t tv = 0;
-      bool has;
-      for (;;) {
+    }
+    // ---- chain across the regions: fixed point ----------------------------------------------------
+    // in_abs = stream position at which the element chain arrives at my region (>= rs).  Lane 0
+    // knows it (e_abs), the others start from a guess; every round hands each region's exit to
+    // the next lane, and when nothing changes any more all of them are exact.
+    uint32_t in_abs = rs, out_abs = rs, tv = 0;
+    bool has = false;
+    auto iterate = [&](uint32_t e_abs, uint32_t max_rounds) {
+      if (lane == 0) in_abs = e_abs;
+      for (uint32_t round = 0; round < max_rounds; round++) {
         has = in_abs < rs + kRegion;
         out_abs = in_abs;
         if (has) {
@@ -320,15 +359,38 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
           }
         }
         const uint32_t prev = lane_prev_u32(out_abs);
-        const uint32_t nin = lane == 0 ? entry_abs : prev;
+        const uint32_t nin = lane == 0 ? e_abs : prev;
         const bool changed = nin != in_abs;
         in_abs = nin;
         if (!ballot(changed)) break;
       }
+    };
+    if (SPLIT) {
+      if (dbgt) tt1 = __builtin_amdgcn_s_memtime();
+      // wait for the previous chunk's result
+      uint32_t* m = s_mail[ci & 7];
+      while (__hip_atomic_load(&m[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ci + 1)
+        __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      entry_abs = readfirst(m[1]);
+      op = readfirst(m[2]);
+      const uint32_t fl = readfirst(m[3]);
+      strad_before = (fl & 4) != 0;
+      if (dbgt) tt2 = __builtin_amdgcn_s_memtime();
+      if ((fl & 3) == 2) {  // somebody has written the verdict
+        post(ci + 1, 2, 0, 0, false);
+        return;
+      }
+    }
+    if (entry_abs < c0 + kChunk) {  // otherwise a long literal covers the whole chunk
+      iterate(entry_abs, 0xffffffffu);
 
       // ---- verdicts and this chunk's contribution ---------------------------------------------------
       const bool bad = has && t_exit(tv) == kExitErr;
-      if (ballot(bad)) return finish(kInvalidInput, 0);
+      if (ballot(bad)) {
+        bail(kInvalidInput);
+        return;
+      }
       if (has && in_abs < n) {  // in_abs == n is the end of the stream, not an element
         entry_off = in_abs - rs;
         out_here = t_out(tv);
@@ -341,9 +403,15 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
     // output positions: saturating counts keep the sum below 2^32 (64 * 0x1ffff)
     uint32_t tot;
     const uint32_t before = wave_excl_scan(out_here, lane, &tot);
-    if (op + tot > win_limit) return finish(too_long, 0);
+    if (op + tot > win_limit) {
+      bail(too_long);
+      return;
+    }
     // SPLIT: a saturated length (an element of more than ~127 KiB) cannot be placed: whole-stream kernel
-    if (SPLIT && ballot(out_here >= kOutSat)) return finish(kNeedsStreamKernel, 0);
+    if (SPLIT && ballot(out_here >= kOutSat)) {
+      bail(kNeedsStreamKernel);
+      return;
+    }
 
     const uint32_t pos0 = op + before;
     if (SPLIT) {
@@ -398,12 +466,37 @@ __global__ __launch_bounds__(64) void index_units_kernel(IndexParams prm) {
     }
     }
     op += tot;
+    if (SPLIT) {
+      const bool strad = strad_before || ballot(straddle) != 0;
+      if (ended || c0 + kChunk >= n) {  // the walk is complete: I hold the final state
+        uint32_t st = kOk;
+        if (!ended && entry_abs != n) st = kInvalidInput;
+        else if (exact && op != limit) st = kInvalidInput;  // snappy.nim:107-108
+        else if (strad) st = kNeedsStreamKernel;
+        finish(st, st == kOk ? op : 0);
+        post(ci + 1, 2, 0, 0, false);
+        return;
+      }
+      post(ci + 1, 0, entry_abs, op, strad);
+      if (dbgt) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        tA += tt1 - tt0;
+        tW += tt2 - tt1;
+        tC += t3 - tt2;
+      }
+    }
   }
+  if (dbgt && lane == 0 && wave == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(prm.idx);
+    dbg[0] = tA;
+    dbg[1] = tW;
+    dbg[2] = tC;
+  }
+  if (SPLIT) return;  // (my chunks ran out; the wave that owns the last chunk concludes)
 
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
-  if (SPLIT && ballot(straddle)) return finish(kNeedsStreamKernel, 0);
   finish(kOk, op);
 }
 

@@ -738,7 +738,22 @@ int uncompress_split_host(const uint8_t* in, size_t n, uint32_t hdr, uint64_t le
   ip.n_units = 1;
   ip.unit = kUnitRaw;
   ip.blk_in = (uint32_t*)d_blk;
-  hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64), 0, s, ip);
+  unsigned long long* d_sdbg = nullptr;
+  if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+    HIP_TRY(hipMalloc((void**)&d_sdbg, 64));
+    HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
+    ip.idx = (uint32_t*)d_sdbg;
+  }
+  hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
+  if (d_sdbg) {
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, d_sdbg, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double nch = (double)((n + kChunk - 1) / kChunk) / kSplitWaves;
+    fprintf(stderr, "SPLIT STATS wave 0, ticks per own chunk: tables %.0f, mail wait %.0f, chain %.0f\n", h[0] / nch,
+            h[1] / nch, h[2] / nch);
+    (void)hipFree(d_sdbg);
+  }
   std::vector<uint32_t> blk(nblk + 1);
   HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(blk.data(), d_blk, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));

@@ -28,3 +28,18 @@ for rep in range(3):
     print("rep %d: %d MiB framed: compress %.2f GB/s (%.1f ms), uncompress %.2f GB/s (%.1f ms)" % (
         rep, n >> 20, n / (t1 - t0) / 1e9, (t1 - t0) * 1e3, n / (t2 - t1) / 1e9, (t2 - t1) * 1e3), flush=True)
 assert np.array_equal(out, src)
+# raw buffer through snappy_hip_compress / snappy_hip_uncompress
+lib.snappy_hip_max_compressed_len.restype = ctypes.c_uint64
+capr = n + n // 6 + 64
+compr = np.empty(capr, dtype=np.uint8)
+for rep in range(3):
+    t0 = time.perf_counter()
+    st = lib.snappy_hip_compress(P(src), ctypes.c_size_t(n), P(compr), ctypes.c_size_t(capr), ctypes.byref(w))
+    t1 = time.perf_counter()
+    w2 = ctypes.c_size_t(0)
+    st2 = lib.snappy_hip_uncompress(P(compr), ctypes.c_size_t(w.value), P(out), ctypes.c_size_t(n), ctypes.byref(w2))
+    t2 = time.perf_counter()
+    assert st == 0 and st2 == 0 and w2.value == n, (st, st2)
+    print("rep %d: %d MiB raw: compress %.2f GB/s (%.1f ms), uncompress %.2f GB/s (%.1f ms)" % (
+        rep, n >> 20, n / (t1 - t0) / 1e9, (t1 - t0) * 1e3, n / (t2 - t1) / 1e9, (t2 - t1) * 1e3), flush=True)
+assert np.array_equal(out, src)
