@@ -643,15 +643,27 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   out_len->assign(nu, 0);
   crc->assign(nu, 0);
   if (nu == 0) return SNAPPY_HIP_OK;
+  // stored chunks (plain copies) are put behind the compressed units, so that those can take the
+  // indexed decoder as one uniform batch; results are mapped back below
+  std::vector<uint32_t> perm(nu);
+  size_t n_front = 0;
+  {
+    size_t back = nu;
+    for (size_t i = 0; i < nu; i++)
+      if (units[i].kind != (uint8_t)kUnitStored) perm[n_front++] = (uint32_t)i;
+    for (size_t i = nu; i-- > 0;)
+      if (units[i].kind == (uint8_t)kUnitStored) perm[--back] = (uint32_t)i;
+  }
   std::vector<uint64_t> io(nu), oo(nu);
   std::vector<uint32_t> il(nu), oc(nu);
   std::vector<uint8_t> kd(nu);
-  for (size_t i = 0; i < nu; i++) {
-    io[i] = units[i].in_off;
-    il[i] = units[i].in_len;
-    oo[i] = units[i].out_off;
-    oc[i] = units[i].out_cap;
-    kd[i] = units[i].kind;
+  for (size_t k = 0; k < nu; k++) {
+    const HostUnit& un = units[perm[k]];
+    io[k] = un.in_off;
+    il[k] = un.in_len;
+    oo[k] = un.out_off;
+    oc[k] = un.out_cap;
+    kd[k] = un.kind;
   }
   void *d_in, *d_out, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_kd, *d_crc;
   if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
@@ -672,14 +684,19 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   HIP_TRY(hipMemcpyAsync(d_oc, oc.data(), nu * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_kd, kd.data(), nu, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_ol, 0, nu * 4, s));
-  // uniform batches (no stored chunks among them) take the indexed decoder
-  bool uniform = true;
-  for (size_t i = 1; i < nu; i++) uniform = uniform && kd[i] == kd[0];
-  uniform = uniform && kd[0] != (uint8_t)kUnitStored;
-  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nu,
-                     uniform ? (int)kd[0] : 0, uniform ? nullptr : (const uint8_t*)d_kd,
-                     (uint8_t*)d_out, (const uint64_t*)d_oo,
-                     (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+  // the compressed units take the indexed decoder when they are all of one kind; stored chunks
+  // (and mixed kinds) take the one-pass kernel with per-unit kinds
+  bool uniform = n_front > 0;
+  for (size_t i = 1; i < n_front; i++) uniform = uniform && kd[i] == kd[0];
+  const size_t n_a = uniform ? n_front : 0;  // units [0, n_a): uniform batch; [n_a, nu): per-unit kinds
+  if (n_a && (st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, n_a,
+                            (int)kd[0], nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
+                            (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+    return st;
+  if (n_a < nu && (st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io + n_a,
+                                 (const uint32_t*)d_il + n_a, nu - n_a, 0, (const uint8_t*)d_kd + n_a,
+                                 (uint8_t*)d_out, (const uint64_t*)d_oo + n_a, (const uint32_t*)d_oc + n_a,
+                                 (uint32_t*)d_ol + n_a, (uint32_t*)d_st + n_a, true, s)))
     return st;
   if (want_crc) {
     // CRC of what each unit produced (decoded bytes / stored bytes), snappy.nim:231, :245
@@ -693,6 +710,13 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   if (out_bytes && copy_out)
     HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  {  // back to the caller's unit order
+    std::vector<uint32_t> t(nu);
+    for (std::vector<uint32_t>* v : {status, out_len, crc}) {
+      for (size_t k = 0; k < nu; k++) t[perm[k]] = (*v)[k];
+      *v = t;
+    }
+  }
   return SNAPPY_HIP_OK;
 }
 
