@@ -478,11 +478,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           }
         }
         if (__builtin_expect(run_end > g + kGroup, 0)) {
-          // ---- run extension: out[x] = out[x - W], W = a multiple of the offset >= 256, so a
-          // trip only reads what earlier trips (or earlier groups) wrote; one dword per lane ----
+          // ---- run extension: out[x] = out[x - W]; W >= 256, so a trip only reads what earlier
+          // trips (or earlier groups) wrote; one dword per lane ----
           acc_a++;
-          uint32_t W = run_off;
-          while (W < kGroup) W <<= 1;
+          // W = the smallest multiple of the offset that is >= 256: then W - offset < 256, i.e. for
+          // x >= g + 256 the source x - W is not below g - offset, the first byte the run's own
+          // chain of copies reaches from x (a larger multiple could read bytes from before the run)
+          const uint32_t W = run_off * ((kGroup - 1 + run_off) / run_off);
           cbar();
           for (uint32_t x = g + kGroup + 4 * lane; x < run_end; x += kGroup) {
             const uint32_t src = x - W;

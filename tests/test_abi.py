@@ -81,3 +81,40 @@ def test_fails_loudly_without_gpu(hip):
         hip.masked_crc(b"123456789")
     with pytest.raises(hip.DeviceError):
         hip.Context(0)
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    exe = str(tmp_path / "roundtrip")
+    lib_dir = os.path.join(ROOT, "nim-snappy_amd")
+    subprocess.run([cc, "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "roundtrip.c"),
+                    "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lsnappy_hip",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return subprocess.run([exe], capture_output=True, text=True)
+
+
+def test_c_consumer_links_and_fails_loudly_without_gpu(hip, tmp_path):
+    """examples/roundtrip.c, a plain C program, links against the shared library through
+    include/snappy_hip.h alone (what a Nim importc / cgo binding does); without a GPU its first
+    codec call reports SNAPPY_HIP_DEVICE_ERROR (exit code 2) instead of silently using a CPU path"""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    res = _build_c_example(tmp_path)
+    if has_gpu:
+        assert res.returncode == 0, res.stdout + res.stderr
+    else:
+        assert res.returncode == 2 and "no usable GPU" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_c_consumer_round_trips_on_gpu(hip, tmp_path):
+    res = _build_c_example(tmp_path)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "raw:" in res.stdout and "framed:" in res.stdout and "masked crc32c ok" in res.stdout

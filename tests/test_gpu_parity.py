@@ -286,3 +286,28 @@ def test_random_valid_streams_match_oracle(hip, orc):
         raw = _varint(len(plain)) + body
         assert orc.decode(raw) == plain
         assert hip.decode(raw) == plain, i
+
+
+def test_long_same_offset_runs_inside_a_block(hip, orc):
+    """long matches (runs of same-offset copies, encoder.nim:97-112) that start in the middle of a
+    block, right after unrelated data: the decoder's run extension may only reach back into the
+    run itself (found by examples/roundtrip.c)"""
+    base = b"the quick brown fox jumps over the lazy dog "
+    for period, seg in ((44, 7000), (10, 3000), (1, 5000), (200, 9000), (255, 4000), (257, 4000), (300, 6000)):
+        unit = (base * 8)[:period]
+        src = bytes((unit[i % period] + (i // seg)) & 255 for i in range(200000))
+        comp = orc.encode(src)
+        assert hip.encode(src) == comp
+        assert hip.decode(comp) == src, (period, seg)
+        body = orc.encode_block(src[:65536])
+        assert hip.decode_all_tags(body, 65536) == (0, src[:65536]), (period, seg)
+
+
+def test_stream_adapters(hip):
+    """the batching stream front-ends (snappy/faststreams.nim, snappy/streams.nim restated in
+    nim-snappy_amd/streams.py) over the HIP codec: same checks as with the oracle backend"""
+    import test_streams
+    test_streams.check_adapters(hip, 2)
+    test_streams.check_adapters(hip, 256)
+    test_streams.check_adapter_errors(hip, 2)
+    test_streams.check_adapter_errors(hip, 256)
