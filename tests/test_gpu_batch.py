@@ -247,3 +247,63 @@ def test_full_size_round_trip_properties(hip, torch_mod):
     assert bool(torch.equal(d_dec, d_in))
     assert bool(torch.equal(d_crc, d_crc_in))
     ctx.close()
+
+
+def _structured_block(rng, n=65536):
+    """LZ-friendly fuzz: random bytes, repeats of earlier slices at all kinds of distances and
+    lengths, periodic runs, constant and ramp stretches -- the shapes that drive the decoder's
+    special paths (long literals, same-offset runs, self-overlapping and near copies)."""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.random()
+        if k < 0.25 or len(out) < 8:
+            out += rng.randbytes(rng.choice([1, 2, 3, 7, 20, 61, 300, 2000]))
+        elif k < 0.65:
+            off = rng.choice([1, 2, 3, 4, 7, 8, 10, 44, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048,
+                              rng.randint(1, len(out))])
+            off = min(off, len(out))
+            ln = rng.choice([4, 5, 11, 12, 17, 63, 64, 65, 67, 68, 69, 130, 300, 1000, 5000])
+            for _ in range(ln):
+                out.append(out[-off])
+        elif k < 0.85:
+            p = rng.choice([1, 2, 3, 5, 10, 44, 100, 255, 256, 257, 300, 777])
+            unit = rng.randbytes(p)
+            ln = rng.choice([50, 300, 1000, 4000, 20000])
+            out += (unit * (ln // p + 1))[:ln]
+        elif k < 0.93:
+            out += bytes(rng.choice([100, 1000, 9000]))
+        else:
+            s0 = rng.randrange(256)
+            out += bytes((s0 + i) & 255 for i in range(rng.choice([300, 3000])))
+    return bytes(out[:n])
+
+
+def test_structured_fuzz_round_trip(hip, orc, torch_mod):
+    """decode(encode(x)) == x and encode(x) == oracle(x) over structured random blocks"""
+    torch = torch_mod
+    rng = random.Random(99)
+    nb = 384
+    blocks = [_structured_block(rng) for _ in range(nb)]
+    flat = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+    ctx = hip.Context(0)
+    d_in = _dev(torch, flat)
+    d_slots, d_sizes, d_offsets, d_out, total = _encode_pack(hip, torch, ctx, d_in, flat.size, hip.UNIT_RAW)
+    sizes = d_sizes.cpu().numpy()
+    packed = d_out.cpu().numpy()
+    offs = d_offsets.cpu().numpy()
+    for i in range(0, nb, 3):  # the GPU encoder against the oracle
+        want = orc.encode(blocks[i])
+        assert packed[offs[i]:offs[i] + sizes[i]].tobytes() == want, i
+    d_out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+    d_out_cap = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
+    d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+    d_dec = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks(d_out, d_offsets[:nb].contiguous(), d_sizes, nb, d_dec, d_out_off, d_out_cap,
+                      d_out_len, d_status, unit=hip.UNIT_RAW)
+    ctx.sync()
+    assert int((d_status != 0).sum().item()) == 0
+    dec = d_dec.cpu().numpy()
+    bad = [i for i in range(nb) if dec[i * 65536:(i + 1) * 65536].tobytes() != blocks[i]]
+    assert not bad, bad[:8]
+    ctx.close()
