@@ -252,15 +252,25 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       bool big = false;  // a literal longer than 64 bytes ends my region: done below
       uint32_t big_dst = 0, big_len = 0, big_src = 0, big_slot = 0;
       bool bad = false;
+      // the tag and the four bytes after it are fetched one trip ahead: as soon as an element's
+      // size is known the next element's bytes are requested, before this one's stores are issued
+      uint32_t t0 = ring_al(pos + shift), t1 = ring_al(pos + shift + 4), t2 = ring_al(pos + shift + 8);
       while (ballot(live)) {
         acc_a++;
         const uint32_t q = pos + shift;
-        const uint32_t t0 = ring_al(q), t1 = ring_al(q + 4), t2 = ring_al(q + 8);
         const uint32_t w0 = __funnelshift_r(t0, t1, (q & 3) * 8), w1 = __funnelshift_r(t1, t2, (q & 3) * 8);
         const uint32_t b14 = (w0 >> 8) | (w1 << 24);
         bool is_copy;
         uint32_t L, size, hdr, off;
         decode_fast(w0 & 0xff, b14, &is_copy, &L, &size, &hdr, &off);
+        {
+          const uint32_t qn = q + (live ? size : 0);
+          cbar();
+          t0 = ring_al(qn);
+          t1 = ring_al(qn + 4);
+          t2 = ring_al(qn + 8);
+          cbar();
+        }
         const bool cpy = live && is_copy;
         const bool lit = live && !is_copy;
         const bool bad_off = cpy && (off == 0 || off > dst);  // decoder.nim:112
@@ -431,14 +441,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
             if (!ballot(dep[0] || dep[1] || dep[2] || dep[3])) break;
           }
         }
-        // ---- gather early; bytes whose source was not final yet are fetched again below ------------
-        const bool stale = (cp[0] && sp[0] < g && sp[0] >= front) || (cp[1] && sp[1] < g && sp[1] >= front) ||
-                           (cp[2] && sp[2] < g && sp[2] >= front) || (cp[3] && sp[3] < g && sp[3] >= front);
         cbar();
-        uint32_t v = 0;
-        if (work)
-          v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
-              ((uint32_t)s_out[sp[3]] << 24);
         // how many of the groups after mine are skipped: I publish them with mine
         uint32_t nskip = 0;
         // (only looked into when the next group starts inside a long literal)
@@ -463,10 +466,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         }
         if (front > expect) continue;  // covered by a run extension meanwhile
         if (work) {
-          if (ballot(stale)) {
-            v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) | ((uint32_t)s_out[sp[2]] << 16) |
-                ((uint32_t)s_out[sp[3]] << 24);
-          }
+          // every source is final now: gather (most groups would have to fetch again after an early
+          // gather anyway, and the CU is issue-bound, not latency-bound)
+          const uint32_t v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) |
+                             ((uint32_t)s_out[sp[2]] << 16) | ((uint32_t)s_out[sp[3]] << 24);
           // the whole dword is this step's: its other bytes are final (literals) and may be rewritten
           // with their own value; the step's first and last dword are stored bytewise (the front end
           // may be writing the next step's literals into the same dword right now)
