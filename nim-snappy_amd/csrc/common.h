@@ -67,6 +67,26 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
   return x - v;
 }
 
+// Exclusive prefix MAXIMUM over the 64 lanes (0 for lane 0); *total receives the wave maximum.
+__device__ __forceinline__ uint32_t wave_excl_scan_max(uint32_t v, uint32_t lane, uint32_t* total) {
+  uint32_t x = v;
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  x = mx(x, dpp_mov0<0x111>(x));  // row_shr:1 (lanes without a source read 0, the identity)
+  x = mx(x, dpp_mov0<0x112>(x));
+  x = mx(x, dpp_mov0<0x114>(x));
+  x = mx(x, dpp_mov0<0x118>(x));
+  {
+    const uint32_t t = dpp_mov0<0x142>(x);  // row_bcast:15
+    if ((lane & 31) >= 16) x = mx(x, t);
+  }
+  {
+    const uint32_t t = dpp_mov0<0x143>(x);  // row_bcast:31
+    if (lane >= 32) x = mx(x, t);
+  }
+  *total = readlane(x, 63);
+  return dpp_mov0<0x138>(x);  // wave_shr:1: the inclusive maximum of the lane before me
+}
+
 // Little-endian unaligned accessors.  gfx950 runs with unaligned global / LDS access enabled;
 // hipcc lowers these to single global_load_dword / ds_read_b32 style instructions.
 template <typename P>

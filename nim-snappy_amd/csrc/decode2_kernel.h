@@ -339,7 +339,6 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       const uint16_t* const o16 = s_off[buf];
       const uint16_t* const d16 = s_dst[buf];
       uint16_t* const r16 = s_r16[wave - 2];
-      uint32_t* const r32 = reinterpret_cast<uint32_t*>(r16);
       const uint32_t gfirst = cb & ~(kGroup - 1);
       // a group in the middle of one long literal holds no copy (the front end flags the
       // boundaries such a literal covers); nobody works on it, the group before it publishes it
@@ -359,18 +358,31 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         // the element that covers byte g is E0 (none in the step's first group when it starts
         // inside it); the elements after it that start inside the group set their start bits
         const uint32_t E0 = g > cb ? (ge & 0x7fffu) : (g == cb ? 0u : 0xffffffffu);
-        if (lane < kGroup / 32) r32[lane] = 0;
+        // every element after E0 that starts inside the group writes its index (1 = E0 + 1, ...) at
+        // its first byte's slot of the scratch; "which element covers byte x" is then the largest
+        // index at or below x: a prefix maximum.  (Slot 0 cannot hold a start -- E0 covers byte g
+        // -- and serves as the sink of the lanes that have nothing to write.)
+        *reinterpret_cast<uint2*>(r16 + 4 * lane) = make_uint2(0, 0);
         cbar();
         for (uint32_t e = E0 + 1 + lane;; e += 64) {
           const uint32_t d = e < count ? (uint32_t)d16[e] : 0xffffffffu;
           const bool in = d < g + kGroup;  // (d > g: the list is in output order)
-          const uint32_t rel = in ? d - g : 0;
-          atomicOr(r32 + (rel >> 5), in ? 1u << (rel & 31) : 0u);
+          r16[in ? d - g : 0] = (uint16_t)(e - E0);
           if (ballot(in) != ~0ull) break;
         }
         cbar();
-        const uint32_t wbits = r32[lane >> 3];
+        const uint2 rv = *reinterpret_cast<const uint2*>(r16 + 4 * lane);
         cbar();
+        uint32_t li[4];  // index (relative to E0) of the element that covers each of my bytes
+        li[0] = lane == 0 ? 0 : (rv.x & 0xffffu);
+        li[1] = rv.x >> 16;
+        li[2] = rv.y & 0xffffu;
+        li[3] = rv.y >> 16;
+        li[1] = li[1] > li[0] ? li[1] : li[0];
+        li[2] = li[2] > li[1] ? li[2] : li[1];
+        li[3] = li[3] > li[2] ? li[3] : li[2];
+        uint32_t tot;  // elements that start inside the group
+        const uint32_t before = wave_excl_scan_max(li[3], lane, &tot);
         // my bytes that belong to this step: [lo, hi) of 0..4
         uint32_t rmask = 15;
         if (g < cb || g + kGroup > cn) {  // only the step's first and last group are partial
@@ -378,15 +390,12 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
           rmask = ((1u << hi) - 1) & ~((1u << lo) - 1);
         }
-        const uint32_t cbits = (wbits >> ((4 * lane) & 31)) & rmask;
-        uint32_t tot;
-        const uint32_t excl = wave_excl_scan((uint32_t)__builtin_popcount(cbits), lane, &tot);
         uint32_t sp[4], offj[4];
         bool cp[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
           const bool in = (rmask >> j) & 1;
-          const uint32_t ei = E0 + excl + (uint32_t)__builtin_popcount(cbits & ((2u << j) - 1));
+          const uint32_t ei = E0 + (li[j] > before ? li[j] : before);
           const uint32_t off = o16[in ? ei : 0];
           cp[j] = in && off != 0;
           offj[j] = cp[j] ? off : 0;
