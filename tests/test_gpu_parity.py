@@ -311,3 +311,17 @@ def test_stream_adapters(hip):
     test_streams.check_adapters(hip, 256)
     test_streams.check_adapter_errors(hip, 2)
     test_streams.check_adapter_errors(hip, 256)
+
+
+def test_long_foreign_block_streams_take_the_one_pass_kernel(hip, orc):
+    """a block whose tag stream is longer than the indexed decoder takes (> 80 KiB for <= 64 KiB of
+    output: only a foreign encoder writes that) is handed to the one-pass kernel: same result"""
+    rng = random.Random(3)
+    plain = rng.randbytes(50000)
+    body = b"".join(bytes([0x00, b]) for b in plain)  # 1-byte literals: 2 stream bytes per byte
+    assert len(body) > 81920
+    assert orc.decode_all_tags(body, len(plain)) == (0, plain)
+    assert hip.decode_all_tags(body, len(plain)) == (0, plain)
+    raw = _varint(len(plain)) + body
+    assert hip.decode(raw) == plain
+    assert hip.uncompress(raw[:-1], len(plain))[0] == orc.uncompress(raw[:-1], len(plain))[0] != bh.OK
