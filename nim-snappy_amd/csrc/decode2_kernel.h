@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   uint8_t* const s_out = s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave
-  __shared__ __attribute__((aligned(8))) uint16_t s_r16[kD2Pool][kGroup];
+  __shared__ __attribute__((aligned(16))) uint16_t s_r16[kD2Pool][kGroup];
   // element lists of the current and the previous step, in stream order
   __shared__ __attribute__((aligned(4))) uint16_t s_off[2][kElemCap];  // copy offset, 0 = literal
   __shared__ __attribute__((aligned(4))) uint16_t s_dst[2][kElemCap];  // first output byte
@@ -348,21 +348,24 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         return (a & 0x8000u) && gg + kGroup < cn && a == b2;
       };
       uint32_t front = cb;  // what I know of s_front
+      constexpr uint32_t B = kGroup / 64;  // bytes per lane (4 or 8): one or two aligned dwords
       for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn; g += kD2Pool * kGroup) {
         const uint32_t ge = g > cb ? readfirst((uint32_t)s_gidx[g / kGroup]) : 0;
         if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
-        const uint32_t p = g + 4 * lane;
+        const uint32_t p = g + B * lane;
         front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (front > (g > cb ? g : cb)) continue;  // a run extension (below) has covered my group
         // the element that covers byte g is E0 (none in the step's first group when it starts
-        // inside it); the elements after it that start inside the group set their start bits
+        // inside it)
         const uint32_t E0 = g > cb ? (ge & 0x7fffu) : (g == cb ? 0u : 0xffffffffu);
         // every element after E0 that starts inside the group writes its index (1 = E0 + 1, ...) at
         // its first byte's slot of the scratch; "which element covers byte x" is then the largest
         // index at or below x: a prefix maximum.  (Slot 0 cannot hold a start -- E0 covers byte g
         // -- and serves as the sink of the lanes that have nothing to write.)
-        *reinterpret_cast<uint2*>(r16 + 4 * lane) = make_uint2(0, 0);
+        uint32_t* const r32 = reinterpret_cast<uint32_t*>(r16 + B * lane);  // my B slots
+#pragma unroll
+        for (uint32_t k = 0; k < B / 2; k++) r32[k] = 0;
         cbar();
         for (uint32_t e = E0 + 1 + lane;; e += 64) {
           const uint32_t d = e < count ? (uint32_t)d16[e] : 0xffffffffu;
@@ -371,83 +374,92 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           if (ballot(in) != ~0ull) break;
         }
         cbar();
-        const uint2 rv = *reinterpret_cast<const uint2*>(r16 + 4 * lane);
+        uint32_t li[B];  // index (relative to E0) of the element that covers each of my bytes
+#pragma unroll
+        for (uint32_t k = 0; k < B / 2; k++) {
+          const uint32_t rv = r32[k];
+          li[2 * k] = rv & 0xffffu;
+          li[2 * k + 1] = rv >> 16;
+        }
         cbar();
-        uint32_t li[4];  // index (relative to E0) of the element that covers each of my bytes
-        li[0] = lane == 0 ? 0 : (rv.x & 0xffffu);
-        li[1] = rv.x >> 16;
-        li[2] = rv.y & 0xffffu;
-        li[3] = rv.y >> 16;
-        li[1] = li[1] > li[0] ? li[1] : li[0];
-        li[2] = li[2] > li[1] ? li[2] : li[1];
-        li[3] = li[3] > li[2] ? li[3] : li[2];
+        li[0] = lane == 0 ? 0 : li[0];
+#pragma unroll
+        for (uint32_t j = 1; j < B; j++) li[j] = li[j] > li[j - 1] ? li[j] : li[j - 1];
         uint32_t tot;  // elements that start inside the group
-        const uint32_t before = wave_excl_scan_max(li[3], lane, &tot);
-        // my bytes that belong to this step: [lo, hi) of 0..4
-        uint32_t rmask = 15;
+        const uint32_t before = wave_excl_scan_max(li[B - 1], lane, &tot);
+        // my bytes that belong to this step: [lo, hi) of 0..B
+        uint32_t rmask = (1u << B) - 1;
         if (g < cb || g + kGroup > cn) {  // only the step's first and last group are partial
-          const uint32_t lo = p >= cb ? 0 : (cb - p < 4 ? cb - p : 4);
-          const uint32_t hi = p + 4 <= cn ? 4 : (cn > p ? cn - p : 0);
+          const uint32_t lo = p >= cb ? 0 : (cb - p < B ? cb - p : B);
+          const uint32_t hi = p + B <= cn ? B : (cn > p ? cn - p : 0);
           rmask = ((1u << hi) - 1) & ~((1u << lo) - 1);
         }
-        uint32_t sp[4], offj[4];
-        bool cp[4];
+        uint32_t sp[B], offj[B];
+        bool cp[B];
+        bool anyc = false, off_differs = false;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) {
+        for (uint32_t j = 0; j < B; j++) {
           const bool in = (rmask >> j) & 1;
           const uint32_t ei = E0 + (li[j] > before ? li[j] : before);
           const uint32_t off = o16[in ? ei : 0];
           cp[j] = in && off != 0;
           offj[j] = cp[j] ? off : 0;
           sp[j] = p + j - offj[j];
+          anyc = anyc || cp[j];
         }
-        const bool anyc = cp[0] || cp[1] || cp[2] || cp[3];
         // A group that is one run of copies with one offset (how the encoder splits a long match,
         // encoder.nim:97-112): if the run goes on, I will also do the whole groups that follow
-        // inside it, 256 bytes per trip, once it is my turn.  run_end = first byte after them.
+        // inside it, one group per trip, once it is my turn.  run_end = first byte after them.
         // (only groups of few, long elements are examined: tot = element starts in the group)
         uint32_t run_off = 0, run_end = 0;
-#ifndef SNAPPY_NO_RUN_EXT
-        if (__builtin_expect(tot <= 8 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0 &&
-            ballot(offj[0] != run_off || offj[1] != run_off || offj[2] != run_off || offj[3] != run_off) == 0, 0)) {
-          uint32_t R = cn;
-          for (uint32_t e = E0 + tot + 1 + lane;; e += 64) {  // elements after those of my group
-            const uint32_t oo = e < count ? (uint32_t)o16[e] : 0;
-            const uint64_t mm = ballot(oo != run_off);
-            if (mm) {
-              const uint32_t ef = readfirst(e) + ctz64(mm);
-              if (ef < count) R = readfirst((uint32_t)d16[ef]);
-              break;
+        if (__builtin_expect(tot <= kGroup / 32 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0, 0)) {
+#pragma unroll
+          for (uint32_t j = 0; j < B; j++) off_differs = off_differs || offj[j] != run_off;
+          if (ballot(off_differs) == 0) {
+            uint32_t R = cn;
+            for (uint32_t e = E0 + tot + 1 + lane;; e += 64) {  // elements after those of my group
+              const uint32_t oo = e < count ? (uint32_t)o16[e] : 0;
+              const uint64_t mm = ballot(oo != run_off);
+              if (mm) {
+                const uint32_t ef = readfirst(e) + ctz64(mm);
+                if (ef < count) R = readfirst((uint32_t)d16[ef]);
+                break;
+              }
             }
+            run_end = R & ~(kGroup - 1);
           }
-          run_end = R & ~(kGroup - 1);
         }
-#endif
         const bool work = ballot(anyc) != 0;  // (a group of literals only has nothing to do)
         // ---- sources inside my own group: follow them to a final byte ----------------------------
-        bool dep[4];
+        bool dep[B];
+        bool anydep = false;
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) dep[j] = cp[j] && sp[j] >= g;
-        if (ballot(dep[0] || dep[1] || dep[2] || dep[3])) {
-          for (uint32_t it = 0; it < 10; it++) {
+        for (uint32_t j = 0; j < B; j++) {
+          dep[j] = cp[j] && sp[j] >= g;
+          anydep = anydep || dep[j];
+        }
+        if (ballot(anydep)) {
+          for (uint32_t it = 0; it < 11; it++) {
             acc_d++;
             // every copy byte publishes its pointer, every other byte "I am final" (0xffff, never a
             // source position); a byte takes over the pointer of the copy byte it points to: the
             // chain length halves per round
             cbar();
-            *reinterpret_cast<uint2*>(r16 + 4 * lane) =
-                make_uint2((cp[0] ? sp[0] : 0xffffu) | ((cp[1] ? sp[1] : 0xffffu) << 16),
-                           (cp[2] ? sp[2] : 0xffffu) | ((cp[3] ? sp[3] : 0xffffu) << 16));
-            cbar();
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
+            for (uint32_t k = 0; k < B / 2; k++)
+              r32[k] = (cp[2 * k] ? sp[2 * k] : 0xffffu) | ((cp[2 * k + 1] ? sp[2 * k + 1] : 0xffffu) << 16);
+            cbar();
+            anydep = false;
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++) {
               const uint32_t t = r16[dep[j] ? sp[j] - g : 0];
               const bool fin = t == 0xffffu;  // my source is a final byte of the group
               sp[j] = (dep[j] && !fin) ? t : sp[j];
               dep[j] = dep[j] && !fin && t >= g;
+              anydep = anydep || dep[j];
             }
             cbar();
-            if (!ballot(dep[0] || dep[1] || dep[2] || dep[3])) break;
+            if (!ballot(anydep)) break;
           }
         }
         cbar();
@@ -477,32 +489,49 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (work) {
           // every source is final now: gather (most groups would have to fetch again after an early
           // gather anyway, and the CU is issue-bound, not latency-bound)
-          const uint32_t v = (uint32_t)s_out[sp[0]] | ((uint32_t)s_out[sp[1]] << 8) |
-                             ((uint32_t)s_out[sp[2]] << 16) | ((uint32_t)s_out[sp[3]] << 24);
-          // the whole dword is this step's: its other bytes are final (literals) and may be rewritten
-          // with their own value; the step's first and last dword are stored bytewise (the front end
-          // may be writing the next step's literals into the same dword right now)
-          const bool full = rmask == 15;
-          *reinterpret_cast<uint32_t*>(s_out + ((full && anyc) ? p : sink)) = v;
-          if (ballot(!full && anyc)) {
+          uint32_t v[B / 4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) s_out[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
+          for (uint32_t k = 0; k < B / 4; k++)
+            v[k] = (uint32_t)s_out[sp[4 * k]] | ((uint32_t)s_out[sp[4 * k + 1]] << 8) |
+                   ((uint32_t)s_out[sp[4 * k + 2]] << 16) | ((uint32_t)s_out[sp[4 * k + 3]] << 24);
+          // a dword that is entirely this step's: its other bytes are final (literals) and may be
+          // rewritten with their own value; the step's first and last dwords are stored bytewise
+          // (the front end may be writing the next step's literals into the same dword right now)
+          bool partial = false;
+#pragma unroll
+          for (uint32_t k = 0; k < B / 4; k++) {
+            const bool full = ((rmask >> (4 * k)) & 15) == 15;
+            const bool any4 = cp[4 * k] || cp[4 * k + 1] || cp[4 * k + 2] || cp[4 * k + 3];
+            *reinterpret_cast<uint32_t*>(s_out + ((full && any4) ? p + 4 * k : sink)) = v[k];
+            partial = partial || (!full && any4);
+          }
+          if (ballot(partial)) {
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++) {
+              const bool full = ((rmask >> (j & ~3u)) & 15) == 15;
+              s_out[(!full && cp[j]) ? p + j : sink + (j & 3)] = (uint8_t)(v[j / 4] >> (8 * (j & 3)));
+            }
           }
         }
         if (__builtin_expect(run_end > g + kGroup, 0)) {
-          // ---- run extension: out[x] = out[x - W]; W >= 256, so a trip only reads what earlier
-          // trips (or earlier groups) wrote; one dword per lane ----
+          // ---- run extension: out[x] = out[x - W]; W >= the group size, so a trip only reads what
+          // earlier trips (or earlier groups) wrote ----
           acc_a++;
-          // W = the smallest multiple of the offset that is >= 256: then W - offset < 256, i.e. for
-          // x >= g + 256 the source x - W is not below g - offset, the first byte the run's own
-          // chain of copies reaches from x (a larger multiple could read bytes from before the run)
+          // W = the smallest multiple of the offset that is >= kGroup: then W - offset < kGroup, i.e.
+          // for x >= g + kGroup the source x - W is not below g - offset, the first byte the run's
+          // own chain of copies reaches from x (a larger multiple could read bytes from before the run)
           const uint32_t W = run_off * ((kGroup - 1 + run_off) / run_off);
           cbar();
-          for (uint32_t x = g + kGroup + 4 * lane; x < run_end; x += kGroup) {
+          for (uint32_t x = g + kGroup + B * lane; x < run_end; x += kGroup) {
             const uint32_t src = x - W;
-            const uint32_t lo32 = *reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
-            const uint32_t hi32 = *reinterpret_cast<const uint32_t*>(s_out + (src & ~3u) + 4);
-            *reinterpret_cast<uint32_t*>(s_out + x) = __funnelshift_r(lo32, hi32, (src & 3) * 8);
+            const uint32_t* a32 = reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
+            uint32_t lo32 = a32[0];
+#pragma unroll
+            for (uint32_t k = 0; k < B / 4; k++) {
+              const uint32_t hi32 = a32[k + 1];
+              *reinterpret_cast<uint32_t*>(s_out + x + 4 * k) = __funnelshift_r(lo32, hi32, (src & 3) * 8);
+              lo32 = hi32;
+            }
           }
           cbar();
           nskip = 0;
