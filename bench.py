@@ -135,10 +135,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hook: BENCH_SHARE_DEVICE=1 BENCH_DIST_BACKEND=gloo lets several ranks share GPU 0, so that
+    # the N > 1 code path can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("BENCH_SHARE_DEVICE"):
+        local = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -227,6 +235,9 @@ def main():
     idx_ms, _ = ctx.kernel_ms(4)               # index_units_kernel
     ctx.timing(False)
     elapsed = shard.max_over_ranks(dist if world > 1 else None, elapsed, dev)
+    # the side numbers are whole-job rates too: all ranks' bytes over the slowest rank's time
+    t_enc = shard.max_over_ranks(dist if world > 1 else None, t_enc, dev)
+    t_fenc = shard.max_over_ranks(dist if world > 1 else None, t_fenc, dev)
 
     # results must be right, or the number is void
     assert int((d_status != 0).sum().item()) == 0, "decode reported errors"
@@ -238,6 +249,7 @@ def main():
     step(crc=d_crc)
     ctx.sync()
     t_fdec = time.perf_counter() - t0
+    t_fdec = shard.max_over_ranks(dist if world > 1 else None, t_fdec, dev)
 
     # ---- measured copy bandwidth of this box: the second roofline denominator of SURVEY 8(d) -------
     torch.cuda.synchronize()
@@ -290,10 +302,10 @@ def main():
                 "launches": dec_launches,
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },
-            "compress_GBps": round(u_bytes / t_enc / 1e9, 3),
+            "compress_GBps": round(world * u_bytes / t_enc / 1e9, 3),
             "compress_kernel_ms": round(enc_ms, 3),
-            "framed_compress_GBps": round(u_bytes / t_fenc / 1e9, 3),
-            "framed_decompress_GBps": round(u_bytes / t_fdec / 1e9, 3),
+            "framed_compress_GBps": round(world * u_bytes / t_fenc / 1e9, 3),
+            "framed_decompress_GBps": round(world * u_bytes / t_fdec / 1e9, 3),
         }
         if world == 1 and not args.no_cpu:
             offs = d_offsets.cpu().numpy()

@@ -307,3 +307,33 @@ def test_structured_fuzz_round_trip(hip, orc, torch_mod):
     bad = [i for i in range(nb) if dec[i * 65536:(i + 1) * 65536].tobytes() != blocks[i]]
     assert not bad, bad[:8]
     ctx.close()
+
+
+def test_bench_contract_and_two_rank_path(hip):
+    """bench.py prints ONE JSON line with the contract's keys; its N > 1 path (block-range shards,
+    barrier, MAX over ranks) is exercised with two ranks that share this box's GPU over gloo
+    (BENCH_SHARE_DEVICE / BENCH_DIST_BACKEND are test hooks: RCCL refuses two ranks on one device)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--blocks", "1024", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True,
+                         text=True, timeout=600)
+    lines = [ln for ln in one.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, one.stdout + one.stderr
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["dtype"] == "u8" and j["vs_baseline"] is None and j["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:] + two.stderr[-2000:]
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0
