@@ -83,16 +83,17 @@ def test_fails_loudly_without_gpu(hip):
         hip.Context(0)
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, cxx=False):
     import shutil
     import subprocess
-    cc = shutil.which("gcc") or shutil.which("cc")
+    cc = shutil.which("g++" if cxx else "gcc") or shutil.which("c++" if cxx else "cc")
     if cc is None:
-        pytest.skip("no C compiler")
-    exe = str(tmp_path / "roundtrip")
+        pytest.skip("no compiler")
+    exe = str(tmp_path / ("roundtrip_cpp" if cxx else "roundtrip"))
     lib_dir = os.path.join(ROOT, "nim-snappy_amd")
-    subprocess.run([cc, "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "roundtrip.c"),
-                    "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lsnappy_hip",
+    src = os.path.join(ROOT, "examples", "roundtrip.cpp" if cxx else "roundtrip.c")
+    subprocess.run([cc, "-O2", "-Wall", "-Werror"] + (["-std=c++17"] if cxx else []) +
+                   [src, "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lsnappy_hip",
                     "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     return subprocess.run([exe], capture_output=True, text=True)
 
@@ -118,3 +119,21 @@ def test_c_consumer_round_trips_on_gpu(hip, tmp_path):
     res = _build_c_example(tmp_path)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "raw:" in res.stdout and "framed:" in res.stdout and "masked crc32c ok" in res.stdout
+
+
+def test_cpp_mirror_header_compiles_and_fails_loudly_without_gpu(hip, tmp_path):
+    """examples/roundtrip.cpp uses nim-snappy_amd/snappy_hip.hpp (snappy::encode / decode /
+    encodeFramed / decodeFramed like snappy.nim:66-82,112-128,157-167,269-290)"""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    res = _build_c_example(tmp_path, cxx=True)
+    assert res.returncode == (0 if has_gpu else 2), res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_round_trips_on_gpu(hip, tmp_path):
+    res = _build_c_example(tmp_path, cxx=True)
+    assert res.returncode == 0, res.stdout + res.stderr
