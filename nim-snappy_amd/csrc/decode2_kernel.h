@@ -310,24 +310,30 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         // every 256-byte boundary the literal covers maps to its slot
         for (uint32_t m = (ed + kGroup - 1) / kGroup + lane; m * kGroup < ed + eL; m += 64)
           s_gidx[m & (kMaxBlockLen / kGroup - 1)] = (uint16_t)(eslot | 0x8000u);  // flag: inside a long literal
-        // 16 bytes per lane and pass, four passes in flight
-        const uint32_t body = eL & ~15u;
+        // destination-aligned: up to 15 head bytes one per lane, then 16-byte pieces whose LDS store
+        // is aligned (the unaligned side is the load from HBM, where it costs next to nothing; an
+        // unaligned LDS dword store costs 10-20 aligned ones), four pieces per lane in flight
+        const uint32_t head = (16 - (ed & 15)) & 15;
+        const uint32_t hd = head < eL ? head : eL;
+        if (lane < hd) s_out[ed + lane] = in0[es + lane];
+        const uint32_t body = (eL - hd) & ~15u;
+        const uint8_t* src = in0 + es + hd;
+        uint8_t* dstp = s_out + ed + hd;  // 16-byte aligned when body > 0
         for (uint32_t i = lane * 16; i < body; i += 4 * 1024) {
-          uint4 v[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (i + j * 1024 < body) __builtin_memcpy(&v[j], in0 + es + i + j * 1024, 16);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (i + j * 1024 < body) {
-              st32u(s_out + ed + i + j * 1024, v[j].x);
-              st32u(s_out + ed + i + j * 1024 + 4, v[j].y);
-              st32u(s_out + ed + i + j * 1024 + 8, v[j].z);
-              st32u(s_out + ed + i + j * 1024 + 12, v[j].w);
-            }
-          }
+          // (loads from clamped addresses instead of guarded ones: no private array, no spills)
+          const uint32_t i1 = i + 1024 < body ? i + 1024 : i, i2 = i + 2048 < body ? i + 2048 : i,
+                         i3 = i + 3072 < body ? i + 3072 : i;
+          uint4 v0, v1, v2, v3;
+          __builtin_memcpy(&v0, src + i, 16);
+          __builtin_memcpy(&v1, src + i1, 16);
+          __builtin_memcpy(&v2, src + i2, 16);
+          __builtin_memcpy(&v3, src + i3, 16);
+          *reinterpret_cast<uint4*>(dstp + i) = v0;
+          *reinterpret_cast<uint4*>(dstp + i1) = v1;  // (a clamped piece rewrites piece i with its own bytes)
+          *reinterpret_cast<uint4*>(dstp + i2) = v2;
+          *reinterpret_cast<uint4*>(dstp + i3) = v3;
         }
-        if (body + lane < eL) s_out[ed + body + lane] = in0[es + body + lane];
+        if (hd + body + lane < eL) s_out[ed + hd + body + lane] = in0[es + hd + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
       acc_b += 1;
