@@ -312,26 +312,24 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           s_gidx[m & (kMaxBlockLen / kGroup - 1)] = (uint16_t)(eslot | 0x8000u);  // flag: inside a long literal
         // destination-aligned: up to 15 head bytes one per lane, then 16-byte pieces whose LDS store
         // is aligned (the unaligned side is the load from HBM, where it costs next to nothing; an
-        // unaligned LDS dword store costs 10-20 aligned ones), four pieces per lane in flight
+        // unaligned LDS dword store costs 10-20 aligned ones), eight pieces per lane in flight
         const uint32_t head = (16 - (ed & 15)) & 15;
         const uint32_t hd = head < eL ? head : eL;
         if (lane < hd) s_out[ed + lane] = in0[es + lane];
         const uint32_t body = (eL - hd) & ~15u;
         const uint8_t* src = in0 + es + hd;
         uint8_t* dstp = s_out + ed + hd;  // 16-byte aligned when body > 0
-        for (uint32_t i = lane * 16; i < body; i += 4 * 1024) {
-          // (loads from clamped addresses instead of guarded ones: no private array, no spills)
-          const uint32_t i1 = i + 1024 < body ? i + 1024 : i, i2 = i + 2048 < body ? i + 2048 : i,
-                         i3 = i + 3072 < body ? i + 3072 : i;
-          uint4 v0, v1, v2, v3;
-          __builtin_memcpy(&v0, src + i, 16);
-          __builtin_memcpy(&v1, src + i1, 16);
-          __builtin_memcpy(&v2, src + i2, 16);
-          __builtin_memcpy(&v3, src + i3, 16);
-          *reinterpret_cast<uint4*>(dstp + i) = v0;
-          *reinterpret_cast<uint4*>(dstp + i1) = v1;  // (a clamped piece rewrites piece i with its own bytes)
-          *reinterpret_cast<uint4*>(dstp + i2) = v2;
-          *reinterpret_cast<uint4*>(dstp + i3) = v3;
+        for (uint32_t i = lane * 16; i < body; i += 8 * 1024) {
+          // (loads from clamped addresses instead of guarded ones: no private array, no spills; a
+          // clamped piece rewrites piece i with its own bytes)
+          uint32_t ix[8];
+          uint4 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) ix[j] = i + j * 1024 < body ? i + j * 1024 : i;
+#pragma unroll
+          for (int j = 0; j < 8; j++) __builtin_memcpy(&v[j], src + ix[j], 16);
+#pragma unroll
+          for (int j = 0; j < 8; j++) *reinterpret_cast<uint4*>(dstp + ix[j]) = v[j];
         }
         if (hd + body + lane < eL) s_out[ed + hd + body + lane] = in0[es + hd + body + lane];
       }
