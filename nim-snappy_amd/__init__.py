@@ -238,6 +238,20 @@ def _ptr(t):
     return t.data_ptr()
 
 
+def _after_torch(stream, *tensors):
+    """The context launches on its OWN stream.  Work that PyTorch has queued on its current stream
+    for these tensors (torch.zeros fills, copies, ...) is not ordered against that, so a fill could
+    land after a kernel's result.  When the caller did not pass a stream of their own, wait for
+    PyTorch's current stream first (a few microseconds on an idle stream)."""
+    if stream is not None:
+        return
+    for t in tensors:
+        if t is not None and not isinstance(t, int):
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
+
+
 class Context:
     """One GPU: stream, CRC / probe tables.  Device pointers are torch tensors (or ints)."""
 
@@ -263,6 +277,7 @@ class Context:
 
     def encode_blocks(self, d_in, total_len, d_slots, d_sizes, unit=UNIT_RAW,
                       block_len=MAX_BLOCK_LEN, slot_stride=SLOT_STRIDE, stream=None):
+        _after_torch(stream, d_in, d_slots, d_sizes)
         st = _check_device(lib.snappy_hip_encode_blocks_d(
             self._h, _ptr(d_in), total_len, block_len, unit, _ptr(d_slots), slot_stride,
             _ptr(d_sizes), stream))
@@ -271,6 +286,7 @@ class Context:
 
     def pack(self, d_slots, d_sizes, n_blocks, d_out, d_offsets, base=0,
              slot_stride=SLOT_STRIDE, stream=None):
+        _after_torch(stream, d_slots, d_sizes, d_out, d_offsets)
         st = _check_device(lib.snappy_hip_pack_d(
             self._h, _ptr(d_slots), slot_stride, _ptr(d_sizes), n_blocks, base, _ptr(d_out),
             _ptr(d_offsets), stream))
@@ -279,6 +295,7 @@ class Context:
 
     def decode_blocks(self, d_in, d_in_off, d_in_len, n_units, d_out, d_out_off, d_out_cap,
                       d_out_len, d_status, unit=UNIT_RAW, d_crc=None, stream=None):
+        _after_torch(stream, d_in, d_out)
         st = _check_device(lib.snappy_hip_decode_blocks_d(
             self._h, _ptr(d_in), _ptr(d_in_off), _ptr(d_in_len), n_units, unit, _ptr(d_out),
             _ptr(d_out_off), _ptr(d_out_cap), _ptr(d_out_len), _ptr(d_status), _ptr(d_crc),
@@ -287,6 +304,7 @@ class Context:
             raise ValueError("decode_blocks: status %d" % st)
 
     def crc32c(self, d_in, d_off, d_len, n_units, d_crc, stream=None):
+        _after_torch(stream, d_in, d_crc)
         st = _check_device(lib.snappy_hip_crc32c_d(
             self._h, _ptr(d_in), _ptr(d_off), _ptr(d_len), n_units, _ptr(d_crc), stream))
         if st != OK:

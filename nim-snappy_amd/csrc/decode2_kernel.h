@@ -94,6 +94,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   __shared__ uint32_t s_cnt[2];             // elements in the list
   __shared__ uint32_t s_front;              // every output byte below this position is final
   __shared__ uint32_t s_err;
+  // a long literal that covers whole steps: (first step after it) << 16 | (first step that may be skipped)
+  __shared__ uint32_t s_skip;
   __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup];  // list slot of the element covering byte 256 m
 
   const uint32_t tid = threadIdx.x;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   if (tid == 0) {
     s_front = 0;
+    s_skip = 0;
     s_err = 0;
     s_cnt[0] = 0;
     s_cnt[1] = 0;
@@ -177,13 +180,14 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   // operations of one wave in issue order, one instruction at a time for the whole CU
   auto cbar = [] { asm volatile("" ::: "memory"); };
 
-  if (wave == 1) {  // prologue: first 4 KiB of the stream
+  auto fill_ring = [&](uint32_t step) {  // (wave 1) the 4 KiB of the stream that start with `step`
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const uint32_t q = (lane + 64 * i) * 16;
+      const uint32_t q = step * kChunk + (lane + 64 * i) * 16;
       if (q < q_end) ring_store(q, *reinterpret_cast<const uint4*>(g0 + q));
     }
-  }
+  };
+  if (wave == 1) fill_ring(0);
 
   // Index entries of the NEXT step (mine and the other front-end wave's) are fetched at the start
   // of a step and consumed at the start of the next one, before anything younger is issued, so
@@ -204,6 +208,21 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   uint32_t acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;    // DEBUG counters, flushed once per wave
   for (uint32_t s = 0; s <= n_chunks; s++) {
     if (s_err) break;  // set before the last barrier: every wave sees it here
+    {
+      // Steps that lie entirely inside one long literal hold no element and produce no output of
+      // their own (the literal was copied when its tag was met): instead of paying a barrier and a
+      // prefetch round trip for each of them, go straight to the step where the literal ends.
+      const uint32_t sk = readfirst(s_skip);
+      const uint32_t to = sk >> 16, from = sk & 0xffffu;
+      if (s >= from && s < to) {
+        s = to < n_chunks ? to : n_chunks;
+        if (wave == 1 && s < n_chunks) fill_ring(s);
+        ie_pref = idx_at(s * 128 + half * 64 + lane);
+        io_pref = idx_at(s * 128 + (1 - half) * 64 + lane);
+        pq[0] = pq[1] = 0xffffffffu;  // nothing in flight for the ring
+        __syncthreads();
+      }
+    }
     const unsigned long long tm0 = prm.stats ? __builtin_amdgcn_s_memtime() : 0;
     // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
     // everything fetched during the previous step is consumed here, BEFORE new loads are issued
@@ -307,6 +326,11 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const uint32_t ed = readlane(big_dst, e);
         const uint32_t es = readlane(big_src, e);
         const uint32_t eslot = readlane(big_slot, e);
+        {
+          // steps s+2 .. to-1 lie inside this literal (s+1 still has to resolve this step's list)
+          const uint32_t to = (es + eL) / kChunk;
+          if (to > s + 2 && lane == 0) atomicMax(&s_skip, (to << 16) | (s + 2));
+        }
         // every 256-byte boundary the literal covers maps to its slot
         for (uint32_t m = (ed + kGroup - 1) / kGroup + lane; m * kGroup < ed + eL; m += 64)
           s_gidx[m & (kMaxBlockLen / kGroup - 1)] = (uint16_t)(eslot | 0x8000u);  // flag: inside a long literal
@@ -353,7 +377,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       };
       uint32_t front = cb;  // what I know of s_front
       constexpr uint32_t B = kGroup / 64;  // bytes per lane (4 or 8): one or two aligned dwords
-      for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn; g += kD2Pool * kGroup) {
+      // (an empty step has nothing to resolve -- and after a fast-forward its list is not even its own)
+      for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn && cb < cn; g += kD2Pool * kGroup) {
         const uint32_t ge = g > cb ? readfirst((uint32_t)s_gidx[g / kGroup]) : 0;
         if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         cbar();
         for (uint32_t e = E0 + 1 + lane;; e += 64) {
           const uint32_t d = e < count ? (uint32_t)d16[e] : 0xffffffffu;
-          const bool in = d < g + kGroup;  // (d > g: the list is in output order)
+          const bool in = d - g < kGroup;  // (d > g: the list is in output order)
           r16[in ? d - g : 0] = (uint16_t)(e - E0);
           if (ballot(in) != ~0ull) break;
         }
