@@ -550,8 +550,14 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           // for x >= g + kGroup the source x - W is not below g - offset, the first byte the run's
           // own chain of copies reaches from x (a larger multiple could read bytes from before the run)
           const uint32_t W = run_off * ((kGroup - 1 + run_off) / run_off);
+          // ... and once the run is long enough behind x, 1 KiB per trip (16 bytes per lane) with W4,
+          // the smallest multiple >= 1024: x - W4 >= g - offset needs x >= g + W4 - offset
+          const uint32_t W4 = run_off * ((1023 + run_off) / run_off);
+          uint32_t x1 = (g + W4 - run_off + kGroup - 1) & ~(kGroup - 1);  // first group start that may use W4
+          x1 = x1 > g + kGroup ? x1 : g + kGroup;
+          x1 = x1 < run_end ? x1 : run_end;
           cbar();
-          for (uint32_t x = g + kGroup + B * lane; x < run_end; x += kGroup) {
+          for (uint32_t x = g + kGroup + B * lane; x < x1; x += kGroup) {
             const uint32_t src = x - W;
             const uint32_t* a32 = reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
             uint32_t lo32 = a32[0];
@@ -561,6 +567,16 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
               *reinterpret_cast<uint32_t*>(s_out + x + 4 * k) = __funnelshift_r(lo32, hi32, (src & 3) * 8);
               lo32 = hi32;
             }
+          }
+          cbar();
+          for (uint32_t x = x1 + 16 * lane; x < run_end; x += 1024) {  // (x1, run_end: multiples of 256)
+            const uint32_t src = x - W4;
+            const uint32_t* a32 = reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
+            const uint32_t r0 = a32[0], r1 = a32[1], r2 = a32[2], r3 = a32[3], r4 = a32[4];
+            const uint32_t sh8 = (src & 3) * 8;
+            *reinterpret_cast<uint4*>(s_out + x) =
+                make_uint4(__funnelshift_r(r0, r1, sh8), __funnelshift_r(r1, r2, sh8),
+                           __funnelshift_r(r2, r3, sh8), __funnelshift_r(r3, r4, sh8));
           }
           cbar();
           nskip = 0;
