@@ -31,6 +31,7 @@ for cls in classes:
                               d_out_cap, d_out_len, d_status)
             ctx.sync()
             ms, n = ctx.kernel_ms(0)
+            ims, _ = ctx.kernel_ms(4)
             ctx.timing(False)
-        print(cls, "dbg", dbg, "ms %.3f" % ms, "per-block us (512 concurrent) %.1f" % (ms * 1e3 * 512 / nb),
+        print(cls, "dbg", dbg, "ms %.3f" % ms, "index ms %.3f" % ims, "per-block us (512 concurrent) %.1f" % (ms * 1e3 * 512 / nb),
               "C/block %d" % (tot // nb), flush=True)
