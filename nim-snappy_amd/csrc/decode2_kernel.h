@@ -76,6 +76,45 @@ __device__ __forceinline__ void decode_fast(uint32_t tag, uint32_t b14, bool* is
   *size = t == 0 ? 1 + lenlen + Llit : (t == 1 ? 2 : (t == 2 ? 3 : 5));
 }
 
+// The copy loops of a run extension (see the resolver), out of line: they are cold for text-like
+// data, and keeping them out of the resolver's loop keeps that loop's code and registers tight.
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+__device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, uint32_t run_end, uint32_t run_off,
+                                                     uint32_t lane) {
+  // W = the smallest multiple of the offset that is >= kGroup: then W - offset < kGroup, i.e. for
+  // x >= g + kGroup the source x - W is not below g - offset, the first byte the run's own chain of
+  // copies reaches from x (a larger multiple could read bytes from before the run)
+  const uint32_t W = run_off * ((kGroup - 1 + run_off) / run_off);
+  // ... and once the run is long enough behind x, 1 KiB per trip (16 bytes per lane) with W4, the
+  // smallest multiple >= 1024: x - W4 >= g - offset needs x >= g + W4 - offset
+  const uint32_t W4 = run_off * ((1023 + run_off) / run_off);
+  uint32_t x1 = (g + W4 - run_off + kGroup - 1) & ~(kGroup - 1);  // first group start that may use W4
+  x1 = x1 > g + kGroup ? x1 : g + kGroup;
+  x1 = x1 < run_end ? x1 : run_end;
+  for (uint32_t x = g + kGroup + 4 * lane; x < x1; x += kGroup) {
+    const uint32_t src = x - W;
+    const __attribute__((address_space(3))) uint32_t* a32 =
+        reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(out + (src & ~3u));
+    *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(out + x) =
+        __funnelshift_r(a32[0], a32[1], (src & 3) * 8);
+  }
+  asm volatile("" ::: "memory");
+  for (uint32_t x = x1 + 16 * lane; x < run_end; x += 1024) {  // (x1, run_end: multiples of 256)
+    const uint32_t src = x - W4;
+    const __attribute__((address_space(3))) uint32_t* a32 =
+        reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(out + (src & ~3u));
+    const uint32_t r0 = a32[0], r1 = a32[1], r2 = a32[2], r3 = a32[3], r4 = a32[4];
+    const uint32_t sh8 = (src & 3) * 8;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    v.x = __funnelshift_r(r0, r1, sh8);
+    v.y = __funnelshift_r(r1, r2, sh8);
+    v.z = __funnelshift_r(r2, r3, sh8);
+    v.w = __funnelshift_r(r3, r4, sh8);
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(out + x) = v;
+  }
+}
+
 // The 64 KiB output window is DYNAMIC shared memory (launch with kOutAlloc bytes): with the whole
 // footprint declared statically the compiler derives "at most N waves per SIMD" from it and pads
 // the kernel's VGPR allocation to enforce that -- which can leave no room for the second
@@ -546,38 +585,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           // ---- run extension: out[x] = out[x - W]; W >= the group size, so a trip only reads what
           // earlier trips (or earlier groups) wrote ----
           acc_a++;
-          // W = the smallest multiple of the offset that is >= kGroup: then W - offset < kGroup, i.e.
-          // for x >= g + kGroup the source x - W is not below g - offset, the first byte the run's
-          // own chain of copies reaches from x (a larger multiple could read bytes from before the run)
-          const uint32_t W = run_off * ((kGroup - 1 + run_off) / run_off);
-          // ... and once the run is long enough behind x, 1 KiB per trip (16 bytes per lane) with W4,
-          // the smallest multiple >= 1024: x - W4 >= g - offset needs x >= g + W4 - offset
-          const uint32_t W4 = run_off * ((1023 + run_off) / run_off);
-          uint32_t x1 = (g + W4 - run_off + kGroup - 1) & ~(kGroup - 1);  // first group start that may use W4
-          x1 = x1 > g + kGroup ? x1 : g + kGroup;
-          x1 = x1 < run_end ? x1 : run_end;
+          static_assert(B == 4, "extend_run copies one dword per lane in its first loop");
           cbar();
-          for (uint32_t x = g + kGroup + B * lane; x < x1; x += kGroup) {
-            const uint32_t src = x - W;
-            const uint32_t* a32 = reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
-            uint32_t lo32 = a32[0];
-#pragma unroll
-            for (uint32_t k = 0; k < B / 4; k++) {
-              const uint32_t hi32 = a32[k + 1];
-              *reinterpret_cast<uint32_t*>(s_out + x + 4 * k) = __funnelshift_r(lo32, hi32, (src & 3) * 8);
-              lo32 = hi32;
-            }
-          }
-          cbar();
-          for (uint32_t x = x1 + 16 * lane; x < run_end; x += 1024) {  // (x1, run_end: multiples of 256)
-            const uint32_t src = x - W4;
-            const uint32_t* a32 = reinterpret_cast<const uint32_t*>(s_out + (src & ~3u));
-            const uint32_t r0 = a32[0], r1 = a32[1], r2 = a32[2], r3 = a32[3], r4 = a32[4];
-            const uint32_t sh8 = (src & 3) * 8;
-            *reinterpret_cast<uint4*>(s_out + x) =
-                make_uint4(__funnelshift_r(r0, r1, sh8), __funnelshift_r(r1, r2, sh8),
-                           __funnelshift_r(r2, r3, sh8), __funnelshift_r(r3, r4, sh8));
-          }
+          extend_run((lds_u8*)s_out, g, run_end, run_off, lane);
           cbar();
           nskip = 0;
           for (;;) {
