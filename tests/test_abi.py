@@ -137,3 +137,14 @@ def test_cpp_mirror_header_compiles_and_fails_loudly_without_gpu(hip, tmp_path):
 def test_cpp_mirror_round_trips_on_gpu(hip, tmp_path):
     res = _build_c_example(tmp_path, cxx=True)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_graft_entry_build_in_a_fresh_interpreter():
+    """the driver calls __graft_entry__.build() on its own, not under pytest: nothing may rely on
+    modules that only the test runner happens to have imported"""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; p = g.build(); print(len(p.ABI_SYMBOLS))"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert int(res.stdout.strip().splitlines()[-1]) >= 20
