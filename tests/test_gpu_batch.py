@@ -337,3 +337,27 @@ def test_bench_contract_and_two_rank_path(hip):
     assert len(lines) == 1, two.stdout[-2000:] + two.stderr[-2000:]
     j2 = json.loads(lines[0])
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0
+
+
+def test_sharded_compress_tool_two_ranks(hip):
+    """tools/sharded_compress.py (BASELINE configs[4]): the block-range shards of two ranks, laid end to
+    end at the scanned offsets, are the same bytes as one rank's encoding of the whole input"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "sharded_compress.py")
+    one = subprocess.run([sys.executable, tool, "--blocks-per-gpu", "512", "--verify"], capture_output=True,
+                         text=True, timeout=600)
+    j1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", tool,
+                          "--blocks-per-gpu", "256", "--verify"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert lines, two.stdout[-1500:] + two.stderr[-1500:]
+    j2 = json.loads(lines[-1])
+    assert j1["verified"] is True and j2["verified"] is True
+    assert j2["n_gpus"] == 2 and len(j2["shard_bytes"]) == 2
+    assert j2["uncompressed_bytes"] == j1["uncompressed_bytes"]
+    assert j2["compressed_bytes"] == j1["compressed_bytes"] and sum(j2["shard_bytes"]) == j1["shard_bytes"][0]
