@@ -1081,15 +1081,18 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
   for (size_t i = 0; i < units.size(); i++)
     if (chunks[i].crc_only) units[i].out_off = deliver;
   std::vector<uint32_t> st, ol, crc;
-  std::vector<uint8_t> host_out(deliver + crc_scratch + 1);
-  {
-    snappy_hip_ctx* c;
-    int rc = default_ctx(&c);
-    if (rc) return rc;
-  }
-  int rc = decode_host(in, n, units, host_out.data(), deliver + crc_scratch, check_integrity != 0,
-                       &st, &ol, &crc);
+  snappy_hip_ctx* c;
+  int rc = default_ctx(&c);
   if (rc) return rc;
+  // the decoded bytes stay on the device until the verdict is known: only the chunks in front of
+  // the first failing one are delivered, straight into the caller's buffer
+  rc = decode_host(in, n, units, nullptr, deliver + crc_scratch, check_integrity != 0, &st, &ol, &crc,
+                   false);
+  if (rc) return rc;
+  auto deliver_prefix = [&](size_t bytes) -> int {
+    if (bytes) HIP_TRY(hipMemcpy(out, c->ws[4].p, bytes, hipMemcpyDeviceToHost));
+    return SNAPPY_HIP_OK;
+  };
 
   // ---- first failure in stream order wins ------------------------------------------------------
   size_t ok_wr = 0;
@@ -1107,7 +1110,7 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
       ok_wr += ol[i];
       continue;
     }
-    memcpy(out, host_out.data(), ok_wr);  // chunks before the failing one were delivered
+    if ((rc = deliver_prefix(ok_wr))) return rc;  // chunks before the failing one were delivered
     if (result == -2) {                   // output full at this stored chunk, snappy.nim:253-254
       *read_out = ch.hdr_at;
       *written_out = ok_wr;
@@ -1115,7 +1118,7 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
     }
     return result;
   }
-  memcpy(out, host_out.data(), deliver);
+  if ((rc = deliver_prefix(deliver))) return rc;
   if (terminal >= 0) return terminal;
   if (stop_ok) {
     *read_out = stop_rd;
