@@ -34,6 +34,7 @@ struct CrcParams {
   // fixed-size mode (off == nullptr): unit i = in[i*block_len ..], last one short
   uint64_t total_len;
   uint32_t block_len;
+  const uint8_t* done;  // != nullptr: units with done[u] != 0 already have their CRC (decode2_kernel.h)
 };
 
 // a(x)*b(x) mod P(x), reflected representation (bit 31 = x^0).
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
   const uint32_t t = threadIdx.x;
   const uint64_t u = blockIdx.x;
   if (u >= prm.n_units) return;
+  if (prm.done && prm.done[u]) return;
   for (uint32_t i = t; i < 1024; i += kCrcThreads) (&s_tab[0][0])[i] = prm.stride_tab[i];
   __syncthreads();
 

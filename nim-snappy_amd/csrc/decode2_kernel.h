@@ -30,6 +30,7 @@
 #pragma once
 
 #include "common.h"
+#include "crc_pack_kernels.h"
 #include "index_kernel.h"
 
 namespace snappy_hip {
@@ -58,6 +59,14 @@ struct Decode2Params {
   int unit;
   int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
   unsigned long long* stats;  // DEBUG counters (nullptr = off)
+  // masked CRC32C of every unit's output, computed from the LDS window while it is flushed
+  // (nullptr = not wanted); crc_done[u] = 1 where it was written (the units this kernel declines
+  // are checksummed by crc32c_units_kernel afterwards)
+  uint32_t* crc;
+  uint8_t* crc_done;
+  const uint32_t* crc_tab;  // CrcParams::stride_tab
+  const uint32_t* crc_col;  // CrcParams::col_mul
+  uint32_t crc_k32k;        // x^(8 * 32768) mod P: advances a CRC register over 32 KiB
 };
 
 // Branch-free element decode (decoder.nim:42-109); no validity checks, the index pass did them.
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   // a long literal that covers whole steps: (first step after it) << 16 | (first step that may be skipped)
   __shared__ uint32_t s_skip;
   __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup];  // list slot of the element covering byte 256 m
+  __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -172,6 +182,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_err = 0;
     s_cnt[0] = 0;
     s_cnt[1] = 0;
+    s_crc_acc = 0;
+    s_crc_cnt = 0;
   }
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
@@ -646,6 +658,72 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       } else {
         for (uint32_t k = i; k < total; k++) gout[k] = s_out[k];
       }
+    }
+  }
+  if (prm.crc == nullptr) return;
+
+  // ---- masked CRC32C of s_out[0 .. total) (maskedCrc, snappy/codec.nim:71-75), from the window ----
+  // The column scheme of crc32c_units_kernel (crc_pack_kernels.h) with the message in LDS, run
+  // twice side by side to halve the chain of dependent rows: waves 4-7 take the last 32 KiB,
+  // waves 0-3 what lies in front of them, advanced afterwards over those 32 KiB with one
+  // multiplication by x^(8 * 32768) mod P.
+  uint32_t* const s_ctab = reinterpret_cast<uint32_t*>(s_ring);  // (the ring is free now)
+  for (uint32_t i = tid; i < 1024; i += kD2Threads) s_ctab[i] = prm.crc_tab[i];
+  __syncthreads();
+  constexpr uint32_t kHalf = 32768;
+  const uint32_t split = total > kHalf + 4 ? total - kHalf : 0;  // (a front part is never shorter than 4 bytes)
+  const bool front = wave < 4;
+  const uint32_t base = front ? 0 : split;
+  const uint32_t n_part = front ? split : total - split;
+  const uint32_t t = tid & 255;
+  uint32_t part = 0;  // my column's share of the CRC register
+  if (total < 4) {
+    if (tid == 0) {
+      uint32_t reg = 0xffffffffu;
+      for (uint32_t i = 0; i < total; i++) {
+        reg ^= s_out[i];
+        for (int k = 0; k < 8; k++) reg = (reg >> 1) ^ ((reg & 1) ? kCrcPoly : 0);
+      }
+      part = reg;
+    }
+  } else if (n_part) {
+    const uint32_t rows = (n_part + 1023) / 1024;
+    const int32_t pad = (int32_t)(rows * 1024 - n_part);  // virtual leading zero bytes
+    const uint32_t* const o32 = reinterpret_cast<const uint32_t*>(s_out);
+    const uint32_t sh8 = ((base + n_part) & 3) * 8;        // byte phase of my dwords (0 for whole blocks)
+    uint32_t sreg = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+      const int32_t pos = (int32_t)(r * 1024 + 4 * t) - pad;
+      uint32_t w;
+      if (pos >= 4) {  // aligned dwords + funnel shift (an unaligned LDS dword read costs 10-20 aligned ones)
+        const uint32_t a = (base + (uint32_t)pos) >> 2;
+        w = __funnelshift_r(o32[a], o32[a + 1], sh8);
+      } else {  // touches the part's start: virtual zero padding; the message's start: the 0xffffffff init
+        w = 0;
+        for (int k = 0; k < 4; k++) {
+          const int32_t j = pos + k;
+          if (j >= 0) w |= (uint32_t)(s_out[base + j] ^ ((base == 0 && j < 4) ? 0xff : 0)) << (8 * k);
+        }
+      }
+      const uint32_t x = sreg ^ w;
+      if (r + 1 < rows) {
+        sreg = s_ctab[x & 0xff] ^ s_ctab[256 + ((x >> 8) & 0xff)] ^ s_ctab[512 + ((x >> 16) & 0xff)] ^
+               s_ctab[768 + (x >> 24)];
+      } else {
+        sreg = gf2_mulmod(prm.crc_col[t], x);  // the 4*(256-t) bytes from here to the part's end
+      }
+    }
+    part = sreg;
+  }
+  for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
+  if (front && split) part = gf2_mulmod(prm.crc_k32k, part);  // ... and the 32 KiB behind the front part
+  if (lane == 0) {
+    atomicXor(&s_crc_acc, part);
+    cbar();
+    if (atomicAdd(&s_crc_cnt, 1u) == kD2Threads / 64 - 1) {  // the last wave: every part is in
+      const uint32_t crc = ~atomicOr(&s_crc_acc, 0u);             // crc32c.c:761
+      prm.crc[u] = ((crc >> 15) | (crc << 17)) + kMaskDelta;        // crc32c.c:762
+      prm.crc_done[u] = 1;
     }
   }
 }

@@ -78,6 +78,7 @@ struct snappy_hip_ctx {
   hipStream_t stream = nullptr;
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
+  uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
   DevBuf ws[16];                   // grow-only workspace of the host-buffer API
@@ -185,6 +186,11 @@ extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOutAlloc + 8192));
   std::vector<uint32_t> tab(1024), mul(kCrcThreads), so(kSeqLen), ss(kSeqLen);
   build_crc_tables(tab.data(), mul.data());
+  {
+    uint32_t p = 0x80000000u;  // x^0
+    for (uint32_t i = 0; i < 8 * 32768; i++) p = (p >> 1) ^ ((p & 1) ? kCrcPoly : 0);
+    c->crc_k32k = p;
+  }
   build_probe_sequence(so.data(), ss.data());
   HIP_TRY(hipMalloc((void**)&c->d_crc_tab, tab.size() * 4));
   HIP_TRY(hipMalloc((void**)&c->d_col_mul, mul.size() * 4));
@@ -375,7 +381,8 @@ namespace {
 int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
              const uint32_t* d_in_len, uint64_t n_units, int unit, const uint8_t* d_kind,
              uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
-             uint32_t* d_out_len, uint32_t* d_status, bool stream_pass, hipStream_t s) {
+             uint32_t* d_out_len, uint32_t* d_status, bool stream_pass, hipStream_t s,
+             uint32_t* d_crc = nullptr) {
   if (n_units == 0) return SNAPPY_HIP_OK;
   if (n_units > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
   DecodeParams p{};
@@ -392,6 +399,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   p.unit = unit;
   if (const char* e = getenv("SNAPPY_HIP_DBG")) p.dbg = atoi(e);
   const bool v1 = d_kind != nullptr || getenv("SNAPPY_HIP_DECODE_V1") != nullptr;
+  void* d_done = nullptr;  // per unit: the indexed decode kernel has written its CRC
   if (v1) {
     LaunchTimer lt(c, s, 0);
     hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
@@ -441,6 +449,15 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.n_units = n_units;
     dp.unit = unit;
     if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
+    if (d_crc && !getenv("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
+      if ((st = ws_get(c, 14, n_units, &d_done))) return st;
+      HIP_TRY(hipMemsetAsync(d_done, 0, n_units, s));
+      dp.crc = d_crc;
+      dp.crc_done = (uint8_t*)d_done;
+      dp.crc_tab = c->d_crc_tab;
+      dp.crc_col = c->d_col_mul;
+      dp.crc_k32k = c->crc_k32k;
+    }
     unsigned long long* d_stats = nullptr;
     if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
       HIP_TRY(hipMalloc((void**)&d_stats, 128));
@@ -495,6 +512,19 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     LaunchTimer lt(c, s, 5);
     hipLaunchKernelGGL(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
   }
+  if (d_crc) {  // units that did not get their CRC from the indexed decode kernel (all of them for v1)
+    CrcParams cp{};
+    cp.in = d_out;
+    cp.off = d_out_off;
+    cp.len = d_out_len;
+    cp.crc = d_crc;
+    cp.n_units = n_units;
+    cp.stride_tab = c->d_crc_tab;
+    cp.col_mul = c->d_col_mul;
+    cp.done = (const uint8_t*)d_done;
+    LaunchTimer lt(c, s, 2);
+    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, cp);
+  }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
 }
@@ -508,11 +538,8 @@ extern "C" int snappy_hip_decode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
                                           void* stream) {
   if (unit != kUnitBody && unit != kUnitRaw) return SNAPPY_HIP_INVALID_INPUT;
   hipStream_t s = pick_stream(c, stream);
-  int st = decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off,
-                    d_out_cap, d_out_len, d_status, true, s);
-  if (st) return st;
-  if (d_crc) return snappy_hip_crc32c_d(c, d_out, d_out_off, d_out_len, n_units, d_crc, s);
-  return SNAPPY_HIP_OK;
+  return decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off, d_out_cap,
+                  d_out_len, d_status, true, s, d_crc);
 }
 
 // =============================================================================================
@@ -691,20 +718,18 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   const size_t n_a = uniform ? n_front : 0;  // units [0, n_a): uniform batch; [n_a, nu): per-unit kinds
   if (n_a && (st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, n_a,
                             (int)kd[0], nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
-                            (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+                            (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s,
+                            want_crc ? (uint32_t*)d_crc : nullptr)))
     return st;
   if (n_a < nu && (st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io + n_a,
                                  (const uint32_t*)d_il + n_a, nu - n_a, 0, (const uint8_t*)d_kd + n_a,
                                  (uint8_t*)d_out, (const uint64_t*)d_oo + n_a, (const uint32_t*)d_oc + n_a,
-                                 (uint32_t*)d_ol + n_a, (uint32_t*)d_st + n_a, true, s)))
+                                 (uint32_t*)d_ol + n_a, (uint32_t*)d_st + n_a, true, s,
+                                 want_crc ? (uint32_t*)d_crc + n_a : nullptr)))
     return st;
-  if (want_crc) {
-    // CRC of what each unit produced (decoded bytes / stored bytes), snappy.nim:231, :245
-    if ((st = snappy_hip_crc32c_d(c, (const uint8_t*)d_out, (const uint64_t*)d_oo,
-                                  (const uint32_t*)d_ol, nu, (uint32_t*)d_crc, s)))
-      return st;
-    HIP_TRY(hipMemcpyAsync(crc->data(), d_crc, nu * 4, hipMemcpyDeviceToHost, s));
-  }
+  // (want_crc: the CRC of what each unit produced -- decoded bytes / stored bytes, snappy.nim:231,
+  // :245 -- came with the decode)
+  if (want_crc) HIP_TRY(hipMemcpyAsync(crc->data(), d_crc, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(status->data(), d_st, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_len->data(), d_ol, nu * 4, hipMemcpyDeviceToHost, s));
   if (out_bytes && copy_out)

@@ -361,3 +361,54 @@ def test_sharded_compress_tool_two_ranks(hip):
     assert j2["n_gpus"] == 2 and len(j2["shard_bytes"]) == 2
     assert j2["uncompressed_bytes"] == j1["uncompressed_bytes"]
     assert j2["compressed_bytes"] == j1["compressed_bytes"] and sum(j2["shard_bytes"]) == j1["shard_bytes"][0]
+
+
+def test_decode_crc_ragged_units(hip, orc, torch_mod):
+    """The CRC that comes out of the decode kernel's flush, for unit lengths of every residue mod 4
+    and mod 1024, misaligned output offsets, an empty unit and a unit that errors: each == oracle
+    masked CRC of what the unit produced (maskedCrc, codec.nim:71-75)."""
+    import corpus
+    torch = torch_mod
+    rng = np.random.default_rng(4242)
+    text = corpus.make_blocks(0, 4, only="T_TEXT").reshape(-1)
+    lens = [1, 2, 3, 4, 5, 7, 8, 1023, 1024, 1025, 1027, 2048, 4097, 30001, 65533, 65534, 65535, 65536]
+    lens += [int(x) for x in rng.integers(1, 65537, size=14)]
+    plains = []
+    for i, n in enumerate(lens):
+        s = int(rng.integers(0, text.size - n))
+        plains.append(text[s:s + n].tobytes() if i % 3 else bytes(rng.integers(0, 256, n, dtype=np.uint8)))
+    units = [orc.encode(p) for p in plains]
+    units.append(orc.encode(b""))                      # empty: varint 0 only
+    plains.append(b"")
+    bad = bytearray(orc.encode(plains[9]))
+    bad[3] = 0xff; bad[4] = 0xff                        # breaks the element chain
+    units.append(bytes(bad))
+    plains.append(None)
+    nu = len(units)
+    blob = b"".join(units)
+    in_off = np.cumsum([0] + [len(u) for u in units[:-1]]).astype(np.int64)
+    in_len = np.array([len(u) for u in units], dtype=np.int32)
+    # outputs packed back to back (so most start misaligned)
+    caps = np.array([len(p) if p is not None else len(plains[9]) for p in plains], dtype=np.int32)
+    out_off = np.cumsum([0] + [int(c) + 3 for c in caps[:-1]]).astype(np.int64)
+    ctx = hip.Context(0)
+    d_in = _dev(torch, np.frombuffer(blob + b"\0" * 64, dtype=np.uint8))
+    d_out = torch.zeros(int(out_off[-1]) + int(caps[-1]) + 64, dtype=torch.uint8, device="cuda")
+    d_out_len = torch.zeros(nu, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nu,), 77, dtype=torch.int32, device="cuda")
+    d_crc = torch.zeros(nu, dtype=torch.int32, device="cuda")
+    ctx.decode_blocks(d_in, _dev(torch, in_off), _dev(torch, in_len), nu, d_out, _dev(torch, out_off),
+                      _dev(torch, caps), d_out_len, d_status, unit=hip.UNIT_RAW, d_crc=d_crc)
+    ctx.sync()
+    st = d_status.cpu().numpy()
+    ol = d_out_len.cpu().numpy()
+    crcs = d_crc.cpu().numpy().view(np.uint32)
+    out = d_out.cpu().numpy()
+    for i, p in enumerate(plains):
+        if p is None:
+            assert st[i] != 0
+            continue
+        assert st[i] == 0 and ol[i] == len(p), (i, st[i], ol[i], len(p))
+        assert out[out_off[i]:out_off[i] + len(p)].tobytes() == p, i
+        assert int(crcs[i]) == orc.masked_crc(p), (i, len(p))
+    ctx.close()
