@@ -44,7 +44,7 @@ constexpr uint32_t kRegion = 32;                    // stream bytes per lane
 constexpr uint32_t kChunk = 64 * kRegion;           // stream bytes per wave step
 constexpr uint32_t kRowStride = kRegion + 1;        // LDS row stride in dwords
 constexpr uint32_t kExitEnd = 0, kExitErr = 1;      // exit field: chain ended / invalid element
-constexpr uint32_t kExitFar = 992;                  // exit field >= 992: far exit, k = value-992
+constexpr uint32_t kExitFar = 896;                  // exit field >= 896: far exit = 896 + 32 * (length bytes - 1) + k
 constexpr uint32_t kOutSat = 0x1ffff - 1024;        // saturated element length (> 65536 = invalid); leaves
                                                     // room for the <= 16 x 64 bytes a region's chain adds on top
 constexpr uint32_t kIdxNone = 32;
@@ -325,7 +325,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         // (an error or end entry keeps its exit code; in-region lengths are <= 64, so the 17-bit
         // sum cannot overflow past the saturated terminal element)
         const uint32_t t_in = tn + ((1u << 10) | (L << 15));
-        const uint32_t t_out_of = (nx < kExitFar ? nx : kExitFar + (uint32_t)k) | (1u << 10) | (Ls << 15);
+        // (only a literal with length bytes can reach that far; with their number in the exit code
+        // and its length in the entry itself the chain step needs no second look at the stream)
+        const uint32_t far_code = kExitFar + ((((tag >> 2) - 60) & 3) << 5) + (uint32_t)k;
+        const uint32_t t_out_of = (nx < kExitFar ? nx : far_code) | (1u << 10) | (Ls << 15);
         const uint32_t t = !inside ? t_pack(kExitEnd, 0, 0)
                                    : (!ok ? t_pack(kExitErr, 0, 0) : (inreg ? t_in : t_out_of));
         const uint32_t szb = ok ? (size < 255 ? size : 255) : 255;
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     // knows it (e_abs), the others start from a guess; every round hands each region's exit to
     // the next lane, and when nothing changes any more all of them are exact.
     uint32_t in_abs = rs, out_abs = rs, tv = 0;
+    uint32_t far_pos = 0xffffffffu, far_end = 0;  // the last far exit looked up (per lane)
     bool has = false;
     auto iterate = [&](uint32_t e_abs, uint32_t max_rounds) {
       if (lane == 0) in_abs = e_abs;
@@ -354,15 +358,27 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
           if (ex == kExitEnd || ex == kExitErr) {
             out_abs = 0xffffffffu;  // nothing follows
           } else if (ex >= kExitFar) {
-            // far exit: a long literal at offset ex-992; re-read its header from HBM (rare)
-            const uint32_t fp = rs + (ex - kExitFar);
-            const uint32_t ftag = in0[fp];
-            uint32_t fb = 0;
-            for (uint32_t i = 0; i < 4 && fp + 1 + i < n; i++) fb |= (uint32_t)in0[fp + 1 + i] << (8 * i);
-            bool c;
-            uint32_t L, size, hdr, off;
-            decode_element(ftag, fb, 0xffffffffu, &c, &L, &size, &hdr, &off);
-            out_abs = fp + size;
+            // far exit: a long literal at offset kk of my region; its entry holds its own length
+            const uint32_t kk = (ex - kExitFar) & 31, lenlen = ((ex - kExitFar) >> 5) + 1;
+            const uint32_t fl = t_out(s_tab[row + kk]);
+            if (fl < kOutSat) {
+              out_abs = rs + kk + 1 + lenlen + fl;
+            } else {
+              // saturated (longer than any block: the unit is about to be rejected or handed to the
+              // whole-stream kernel): the exact end from the stream itself, looked up once
+              const uint32_t fp = rs + kk;
+              if (fp != far_pos) {
+                const uint32_t ftag = in0[fp];
+                uint32_t fb = 0;
+                for (uint32_t i = 0; i < 4 && fp + 1 + i < n; i++) fb |= (uint32_t)in0[fp + 1 + i] << (8 * i);
+                bool c;
+                uint32_t L, size, hdr, off;
+                decode_element(ftag, fb, 0xffffffffu, &c, &L, &size, &hdr, &off);
+                far_pos = fp;
+                far_end = fp + size;
+              }
+              out_abs = far_end;
+            }
           } else {
             out_abs = rs + ex;
           }
