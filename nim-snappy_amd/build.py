@@ -24,13 +24,18 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())  # (several ranks may find the library stale at once)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB + ".tmp", os.path.join(CSRC, "snappy_hip.hip"),
+           "-Wno-unused-function", "-o", tmp, os.path.join(CSRC, "snappy_hip.hip"),
            "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
