@@ -299,6 +299,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
     if (fe && s < n_chunks) {
       // =================================== front end ===========================================
+      // (the front end's trips and the resolvers' turns are the two chains a step waits for: their
+      // instructions go first; preparing groups and polling fill the gaps)
+      __builtin_amdgcn_s_setprio(3);
       const uint32_t buf = s & 1;
       const uint32_t c0 = s * kChunk + half * (kChunk / 2);
       const uint32_t e_off = ie & 63;
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (hd + body + lane < eL) s_out[ed + hd + body + lane] = in0[es + hd + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
+      __builtin_amdgcn_s_setprio(0);
       acc_b += 1;
     } else if (!fe && s >= 1 && !(prm.dbg & 2)) {
       // =================================== resolvers ===============================================
@@ -566,6 +570,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           cbar();
         }
         if (front > expect) continue;  // covered by a run extension meanwhile
+        __builtin_amdgcn_s_setprio(3);  // (my turn: on the step's critical path until the publish)
         if (work) {
           // every source is final now: gather (most groups would have to fetch again after an early
           // gather anyway, and the CU is issue-bound, not latency-bound)
@@ -616,6 +621,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         front = front < cn ? front : cn;
         cbar();
         if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     const unsigned long long tm1 = prm.stats ? __builtin_amdgcn_s_memtime() : 0;
