@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     if (fe && s < n_chunks) {
       // =================================== front end ===========================================
       // (the front end's trips and the resolvers' turns are the two chains a step waits for: their
-      // instructions go first; preparing groups and polling fill the gaps)
+      // instructions go first; the preparation of later groups fills the gaps)
       __builtin_amdgcn_s_setprio(3);
       const uint32_t buf = s & 1;
       const uint32_t c0 = s * kChunk + half * (kChunk / 2);
@@ -560,6 +560,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         cbar();
         // ---- my turn: every group below mine has published, i.e. everything below g is final ------
         const uint32_t expect = g > cb ? g : cb;
+        // (from here to the publish this wave is, or is about to be, on the step's critical path)
+        __builtin_amdgcn_s_setprio(3);
         for (uint32_t spin = 0; front < expect; spin++) {
           if ((spin & 1023) == 1023 && (spin > 400000 || s_err != 0)) {
             // cannot happen on a consistent index; never hang the GPU
@@ -569,8 +571,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           cbar();
         }
-        if (front > expect) continue;  // covered by a run extension meanwhile
-        __builtin_amdgcn_s_setprio(3);  // (my turn: on the step's critical path until the publish)
+        if (front > expect) {  // covered by a run extension meanwhile
+          __builtin_amdgcn_s_setprio(0);
+          continue;
+        }
         if (work) {
           // every source is final now: gather (most groups would have to fetch again after an early
           // gather anyway, and the CU is issue-bound, not latency-bound)
