@@ -67,6 +67,7 @@ struct Decode2Params {
   const uint32_t* crc_tab;  // CrcParams::stride_tab
   const uint32_t* crc_col;  // CrcParams::col_mul
   uint32_t crc_k32k;        // x^(8 * 32768) mod P: advances a CRC register over 32 KiB
+  const uint32_t* order;    // workgroup i takes unit order[i] (nullptr: unit i)
 };
 
 // Branch-free element decode (decoder.nim:42-109); no validity checks, the index pass did them.
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
   const uint32_t wave = readfirst(tid >> 6);  // (scalar register: wave-uniform by construction)
-  const uint64_t u = blockIdx.x;
-  if (u >= prm.n_units) return;
+  if (blockIdx.x >= prm.n_units) return;
+  const uint64_t u = prm.order ? prm.order[blockIdx.x] : blockIdx.x;  // (launch order, crc_pack_kernels.h)
   if (prm.status[u] != kOk) return;  // the index pass already decided this unit
   const uint32_t total = prm.out_len[u];
   if (total == 0) return;

@@ -78,6 +78,7 @@ struct IndexParams {
   uint64_t n_units;
   int unit;
   uint32_t* blk_in;  // split mode: stream position (after the varint) where output block k starts
+  const uint32_t* order;  // workgroup i takes unit order[i] (nullptr: unit i)
 };
 
 // Decode "the element that would start here" from its tag and the four bytes after it.
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   } else {
     wave_fence();
   }
-  const uint64_t u = blockIdx.x;
-  if (u >= prm.n_units) return;
+  if (blockIdx.x >= prm.n_units) return;
+  const uint64_t u = prm.order ? prm.order[blockIdx.x] : blockIdx.x;  // (launch order, crc_pack_kernels.h)
   const uint8_t* in0 = prm.in + prm.in_off[u];
   uint32_t n = prm.in_len[u];
   const uint32_t cap = prm.out_cap[u];

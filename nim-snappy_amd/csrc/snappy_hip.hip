@@ -449,6 +449,19 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.n_units = n_units;
     dp.unit = unit;
     if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
+    if (n_units >= 512 && !getenv("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
+      void *d_perm, *d_cnt2;
+      if ((st = ws_get(c, 15, n_units * 4 + kOrderBuckets * 4, &d_perm))) return st;
+      d_cnt2 = (uint8_t*)d_perm + n_units * 4;
+      HIP_TRY(hipMemsetAsync(d_cnt2, 0, kOrderBuckets * 4, s));
+      const uint32_t gb = (uint32_t)((n_units + 1023) / 1024 < 256 ? (n_units + 1023) / 1024 : 256);
+      hipLaunchKernelGGL(order_count_kernel, dim3(gb), dim3(256), 0, s, d_in_len, n_units, (uint32_t*)d_cnt2);
+      hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, (uint32_t*)d_cnt2);
+      hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(256), 0, s, d_in_len, n_units, (uint32_t*)d_cnt2,
+                         (uint32_t*)d_perm);
+      ip.order = (const uint32_t*)d_perm;
+      dp.order = (const uint32_t*)d_perm;
+    }
     if (d_crc && !getenv("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
       if ((st = ws_get(c, 14, n_units, &d_done))) return st;
       HIP_TRY(hipMemsetAsync(d_done, 0, n_units, s));

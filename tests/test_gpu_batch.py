@@ -412,3 +412,57 @@ def test_decode_crc_ragged_units(hip, orc, torch_mod):
         assert out[out_off[i]:out_off[i] + len(p)].tobytes() == p, i
         assert int(crcs[i]) == orc.masked_crc(p), (i, len(p))
     ctx.close()
+
+
+def test_launch_order_large_batch(hip, orc, torch_mod):
+    """3 000 units of very different compressed lengths (the library launches them sorted by length,
+    crc_pack_kernels.h): every unit lands in its own output range, statuses and lengths are per
+    unit, CRCs == oracle; the same batch with the ordering switched off gives the same bytes."""
+    import corpus
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    nb = 3000
+    blocks = corpus.make_blocks(5000, nb)
+    flat = blocks.reshape(-1)
+    ctx = hip.Context(0)
+    d_in = _dev(torch, flat)
+    d_slots, d_sizes, d_offsets, d_packed, total = _encode_pack(hip, torch, ctx, d_in, flat.size, hip.UNIT_RAW)
+    stream = bytearray(d_packed[:total].cpu().numpy().tobytes())
+    in_off = d_offsets.cpu().numpy()[:nb].astype(np.int64).copy()
+    in_len = d_sizes.cpu().numpy().astype(np.int32).copy()
+    expect = [blocks[i].tobytes() for i in range(nb)]
+    for i in range(64):  # the first 64 units: ragged lengths, encoded by the oracle
+        plain = blocks[i][:int(rng.integers(1, 65537))].tobytes()
+        u = orc.encode(plain)
+        in_off[i] = len(stream)
+        in_len[i] = len(u)
+        stream += u
+        expect[i] = plain
+    out_off = np.arange(nb, dtype=np.int64) * 65536
+    cap = np.full(nb, 65536, dtype=np.int32)
+    d_stream = _dev(torch, np.frombuffer(bytes(stream) + b"\0" * 64, dtype=np.uint8))
+    results = []
+    for no_order in (False, True):
+        if no_order:
+            os.environ["SNAPPY_HIP_NO_ORDER"] = "1"
+        try:
+            d_out = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+            d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+            d_crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            ctx.decode_blocks(d_stream, _dev(torch, in_off), _dev(torch, in_len), nb, d_out, _dev(torch, out_off),
+                              _dev(torch, cap), d_out_len, d_status, unit=hip.UNIT_RAW, d_crc=d_crc)
+            ctx.sync()
+        finally:
+            os.environ.pop("SNAPPY_HIP_NO_ORDER", None)
+        assert (d_status.cpu().numpy() == 0).all()
+        ol = d_out_len.cpu().numpy()
+        out = d_out.cpu().numpy()
+        crcs = d_crc.cpu().numpy().view(np.uint32)
+        assert [int(x) for x in ol] == [len(e) for e in expect]
+        for i in list(range(64)) + list(range(64, nb, 97)):
+            assert out[i * 65536:i * 65536 + ol[i]].tobytes() == expect[i], i
+            assert int(crcs[i]) == orc.masked_crc(expect[i]), i
+        results.append((out.copy(), crcs.copy()))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    ctx.close()
