@@ -49,6 +49,7 @@ struct EncodeParams {
   const uint32_t* seq_off;  // probe sequence: offset of probe j from the scan start
   const uint32_t* seq_step; // ... and its step (skip >> 5)
   unsigned long long* stats;  // DEBUG: per-section cycle counters (nullptr = off)
+  const uint32_t* order;      // workgroup i takes block order[i] (nullptr: block i; crc_pack_kernels.h)
 };
 
 __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
@@ -63,8 +64,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ uint16_t s_seq_step[kSeqLen];
 
   const uint32_t lane = lane_id();
-  const uint64_t blk = blockIdx.x;
-  if (blk >= prm.n_blocks) return;
+  if (blockIdx.x >= prm.n_blocks) return;
+  const uint64_t blk = prm.order ? prm.order[blockIdx.x] : blockIdx.x;
 
   const uint64_t in_pos = blk * (uint64_t)prm.block_len;
   const uint8_t* in = prm.in + in_pos;

@@ -81,7 +81,7 @@ struct snappy_hip_ctx {
   uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
-  DevBuf ws[16];                   // grow-only workspace of the host-buffer API
+  DevBuf ws[20];                   // grow-only workspace of the host-buffer API
   bool timing = false;
   struct Timed {
     hipEvent_t a, b;
@@ -127,6 +127,24 @@ struct LaunchTimer {
 
 hipStream_t pick_stream(snappy_hip_ctx* c, void* stream) {
   return stream ? (hipStream_t)stream : c->stream;
+}
+
+// perm (in workspace slot `slot`, after `head` bytes the caller keeps there) = the n items in the
+// order of their keys' buckets (crc_pack_kernels.h): a counting sort in three small launches.
+int launch_order(snappy_hip_ctx* c, const uint32_t* d_keys, uint64_t n, int mode, int slot, size_t head,
+                 hipStream_t s, void** d_perm) {
+  void* base;
+  int st = ws_get(c, slot, head + n * 4 + kOrderBuckets * 4, &base);
+  if (st) return st;
+  uint32_t* perm = (uint32_t*)((uint8_t*)base + head);
+  uint32_t* counts = perm + n;
+  HIP_TRY(hipMemsetAsync(counts, 0, kOrderBuckets * 4, s));
+  const uint32_t gb = (uint32_t)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256);
+  hipLaunchKernelGGL(order_count_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts);
+  hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, counts);
+  hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts, perm);
+  *d_perm = perm;
+  return SNAPPY_HIP_OK;
 }
 
 // CRC tables (crc_pack_kernels.h): generated, the reference's tables are not copied.
@@ -338,6 +356,15 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   p.crc = d_crc;
   p.seq_off = c->d_seq_off;
   p.seq_step = c->d_seq_step;
+  if (nb >= 512 && !getenv("SNAPPY_HIP_NO_ORDER")) {  // launch order: blocks that look alike together
+    void *d_sk, *d_perm;
+    int st = ws_get(c, 16, nb * 8 + kOrderBuckets * 4, &d_sk);
+    if (st) return st;
+    hipLaunchKernelGGL(encode_sketch_kernel, dim3((uint32_t)nb), dim3(64), 0, s, d_in, total_len, block_len, nb,
+                       (uint32_t*)d_sk);
+    if ((st = launch_order(c, (const uint32_t*)d_sk, nb, kOrderBySketch, 16, nb * 4, s, &d_perm))) return st;
+    p.order = (const uint32_t*)d_perm;
+  }
   unsigned long long* d_estats = nullptr;
   if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
     HIP_TRY(hipMalloc((void**)&d_estats, 128));
@@ -450,15 +477,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.unit = unit;
     if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
     if (n_units >= 512 && !getenv("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
-      void *d_perm, *d_cnt2;
-      if ((st = ws_get(c, 15, n_units * 4 + kOrderBuckets * 4, &d_perm))) return st;
-      d_cnt2 = (uint8_t*)d_perm + n_units * 4;
-      HIP_TRY(hipMemsetAsync(d_cnt2, 0, kOrderBuckets * 4, s));
-      const uint32_t gb = (uint32_t)((n_units + 1023) / 1024 < 256 ? (n_units + 1023) / 1024 : 256);
-      hipLaunchKernelGGL(order_count_kernel, dim3(gb), dim3(256), 0, s, d_in_len, n_units, (uint32_t*)d_cnt2);
-      hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, (uint32_t*)d_cnt2);
-      hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(256), 0, s, d_in_len, n_units, (uint32_t*)d_cnt2,
-                         (uint32_t*)d_perm);
+      void* d_perm;
+      if ((st = launch_order(c, d_in_len, n_units, kOrderByLength, 15, 0, s, &d_perm))) return st;
       ip.order = (const uint32_t*)d_perm;
       dp.order = (const uint32_t*)d_perm;
     }
