@@ -24,7 +24,14 @@ d_out = torch.empty(nb * 65536, dtype=torch.uint8, device=dev)
 off0 = d_offsets[:nb].contiguous()
 out_off0 = torch.arange(nb, dtype=torch.int64, device=dev) * 65536
 cap0 = torch.full((nb,), 65536, dtype=torch.int32, device=dev)
+cls = torch.from_numpy(corpus.block_classes(0, nb)).to(dev)
+heavy = torch.nonzero(cls <= 1).flatten()
+cheap = torch.nonzero(cls > 1).flatten()
+k = min(heavy.numel(), cheap.numel())
+alt = torch.stack([heavy[:k], cheap[:k]], dim=1).reshape(-1)
+alt = torch.cat([alt, heavy[k:], cheap[k:]])
 orders = {"corpus order": torch.arange(nb, device=dev),
+          "text/html alternating with the rest": alt,
           "by compressed length, ascending": torch.argsort(d_sizes.to(torch.int64)),
           "by compressed length, descending": torch.argsort(d_sizes.to(torch.int64), descending=True)}
 for name, perm in orders.items():
