@@ -17,7 +17,8 @@
  *
  * Thread safety: like the reference (all `func`, no globals) every call is re-entrant.  The
  * host-buffer calls serialise on one process-wide device context; callers that want
- * concurrency create their own context and use the *_ctx / device entry points.
+ * concurrency create their own context and use the *_ctx / device entry points.  One context
+ * serves one thread (and one stream) at a time: it owns scratch buffers that its calls reuse.
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
