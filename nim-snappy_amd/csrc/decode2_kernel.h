@@ -169,6 +169,46 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   uint8_t* gout = prm.out + prm.out_off[u];
   const uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride);
 
+  // ---- a unit that is ONE literal (what encodeBlock makes of incompressible data, encoder.nim:249-253):
+  // nothing to resolve, nothing to stage -- the payload goes straight from HBM to HBM. ----------------
+  {
+    const uint32_t tag = in0[0];
+    const uint32_t hi6 = tag >> 2;
+    const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
+    if ((tag & 3) == 0 && 1 + lenlen <= n && !(prm.dbg & 64)) {
+      uint32_t L = hi6 + 1;
+      if (lenlen) {
+        uint32_t b = 0;
+        for (uint32_t i = 0; i < lenlen; i++) b |= (uint32_t)in0[1 + i] << (8 * i);
+        L = b + 1;
+      }
+      const uint32_t h = 1 + lenlen;
+      if (L == total && n - h == L) {  // (the index pass has validated the element and the total)
+        const uint8_t* src = in0 + h;
+        if (((uintptr_t)gout & 15) == 0) {
+          for (uint32_t i = tid * 16; i < total; i += kD2Threads * 16) {
+            if (i + 16 <= total) {
+              uint4 v;
+              __builtin_memcpy(&v, src + i, 16);  // (unaligned on the load side, where it is free)
+              *reinterpret_cast<uint4*>(gout + i) = v;
+            } else {
+              for (uint32_t k = i; k < total; k++) gout[k] = src[k];
+            }
+          }
+        } else {
+          for (uint32_t i = tid * 4; i < total; i += kD2Threads * 4) {
+            if (i + 4 <= total) {
+              st32u(gout + i, ld32u(src + i));
+            } else {
+              for (uint32_t k = i; k < total; k++) gout[k] = src[k];
+            }
+          }
+        }
+        return;  // (no CRC here: crc_done stays 0 and the CRC kernel takes the unit)
+      }
+    }
+  }
+
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
   const uint8_t* g0 = in0 - shift;
   const uint32_t q_end = (uint32_t)(((uint64_t)shift + n + 15) & ~15ull);
