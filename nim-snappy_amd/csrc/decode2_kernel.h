@@ -153,34 +153,72 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint32_t wave = readfirst(tid >> 6);  // (scalar register: wave-uniform by construction)
   if (blockIdx.x >= prm.n_units) return;
   const uint64_t u = prm.order ? prm.order[blockIdx.x] : blockIdx.x;  // (launch order, crc_pack_kernels.h)
-  if (prm.status[u] != kOk) return;  // the index pass already decided this unit
+  // The start of a workgroup is a chain of dependent trips to HBM (which unit -> its parameters ->
+  // its first bytes -> its index and stream), and a block's latency is what this kernel is bound by:
+  // everything that can go out together does.  First every per-unit parameter ...
+  const uint32_t st0 = prm.status[u];
   const uint32_t total = prm.out_len[u];
+  const uint64_t in_off = prm.in_off[u];
+  const uint32_t n_all = prm.in_len[u];
+  const uint64_t out_off = prm.out_off[u];
+  const uint64_t idx_base = prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride;
+  if (st0 != kOk) return;  // the index pass already decided this unit
   if (total == 0) return;
 
-  const uint8_t* in0 = prm.in + prm.in_off[u];
-  uint32_t n = prm.in_len[u];
-  if (prm.unit == kUnitRaw) {  // skip the varint (validated by the index pass)
-    uint32_t hdr = 0;
-    while (in0[hdr] & 0x80) hdr++;
-    hdr++;
-    in0 += hdr;
-    n -= hdr;
+  // ... then, knowing only where the unit lies: its first bytes (the varint of a raw unit, the first
+  // tag), the first index entries and the first 4 KiB of the stream.  The ring is laid out from the
+  // unit's first byte, header included, so that its fill does not wait for the header's length.
+  const uint8_t* const unit = prm.in + in_off;
+  uint8_t* gout = prm.out + out_off;
+  const uint32_t* idx = prm.idx + idx_base;
+  uint32_t fb[10];
+#pragma unroll
+  for (uint32_t k = 0; k < 10; k++) fb[k] = unit[k < n_all ? k : n_all - 1];
+  const uint32_t shift0 = (uint32_t)((uintptr_t)unit & 15);
+  const uint8_t* g0 = unit - shift0;
+  const uint32_t q_end = (uint32_t)(((uint64_t)shift0 + n_all + 15) & ~15ull);
+  const uint32_t n_regions0 = (n_all + kSub - 1) / kSub;  // (>= the regions of the tag stream; all inside the unit's index)
+  const bool fe = wave <= 1;                             // front-end waves
+  const uint32_t half = wave == 1 ? 1 : 0;               // which 1 KiB of the step is mine
+  uint4 rf[4];  // (wave 1) the ring's first 4 KiB
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t q = (lane + 64 * i) * 16;
+    rf[i] = make_uint4(0, 0, 0, 0);
+    if (wave == 1 && q < q_end) rf[i] = *reinterpret_cast<const uint4*>(g0 + q);
   }
-  uint8_t* gout = prm.out + prm.out_off[u];
-  const uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride);
+  const uint32_t ie0 = half * 64 + lane < n_regions0 ? idx[half * 64 + lane] : 0;
+  const uint32_t io0 = (1 - half) * 64 + lane < n_regions0 ? idx[(1 - half) * 64 + lane] : 0;
+  const uint32_t sb0 = tid * 128 < n_regions0 ? idx[tid * 128] : 0;  // (kMaxSteps <= the workgroup's threads)
+  static_assert(kMaxSteps <= kD2Threads, "one s_sbase entry per thread");
+
+  uint32_t hdr = 0;
+  if (prm.unit == kUnitRaw) {  // skip the varint (validated by the index pass: at most 5 bytes)
+    while (hdr < 4 && (fb[hdr] & 0x80)) hdr++;
+    hdr++;
+  }
+  const uint8_t* in0 = unit + hdr;
+  const uint32_t n = n_all - hdr;
 
   // ---- a unit that is ONE literal (what encodeBlock makes of incompressible data, encoder.nim:249-253):
   // nothing to resolve, nothing to stage -- the payload goes straight from HBM to HBM. ----------------
   {
-    const uint32_t tag = in0[0];
+    // (fb[hdr ..]: the tag and its length bytes; hdr + 1 + 4 <= 10)
+    uint32_t tb[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) {
+      tb[k] = fb[k];
+#pragma unroll
+      for (uint32_t h2 = 1; h2 <= 5; h2++) tb[k] = hdr == h2 ? fb[k + h2] : tb[k];
+    }
+    const uint32_t tag = tb[0];
     const uint32_t hi6 = tag >> 2;
     const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
     if ((tag & 3) == 0 && 1 + lenlen <= n && !(prm.dbg & 64)) {
       uint32_t L = hi6 + 1;
       if (lenlen) {
-        uint32_t b = 0;
-        for (uint32_t i = 0; i < lenlen; i++) b |= (uint32_t)in0[1 + i] << (8 * i);
-        L = b + 1;
+        const uint32_t b = tb[1] | (tb[2] << 8) | (tb[3] << 16) | (tb[4] << 24);
+        L = (lenlen == 4 ? b : (b & ((1u << (8 * lenlen)) - 1))) + 1;
       }
       const uint32_t h = 1 + lenlen;
       if (L == total && n - h == L) {  // (the index pass has validated the element and the total)
@@ -209,13 +247,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     }
   }
 
-  const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
-  const uint8_t* g0 = in0 - shift;
-  const uint32_t q_end = (uint32_t)(((uint64_t)shift + n + 15) & ~15ull);
+  const uint32_t shift = shift0 + hdr;  // ring position of the tag stream's first byte (<= 20)
   const uint32_t n_chunks = (n + kChunk - 1) / kChunk;   // 2 KiB steps
   const uint32_t n_regions = (n + kSub - 1) / kSub;       // 16-byte index entries
-  const bool fe = wave <= 1;                             // front-end waves
-  const uint32_t half = wave == 1 ? 1 : 0;               // which 1 KiB of the step is mine
 
   if (tid == 0) {
     s_front = 0;
@@ -279,7 +313,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       if (q < q_end) ring_store(q, *reinterpret_cast<const uint4*>(g0 + q));
     }
   };
-  if (wave == 1) fill_ring(0);
+  if (wave == 1) {  // land what was fetched at the start
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t q = (lane + 64 * i) * 16;
+      if (q < q_end) ring_store(q, rf[i]);
+    }
+  }
 
   // Index entries of the NEXT step (mine and the other front-end wave's) are fetched at the start
   // of a step and consumed at the start of the next one, before anything younger is issued, so
@@ -288,10 +328,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   auto idx_at = [&](uint32_t r) -> uint32_t { return r < n_regions ? idx[r] : none_end; };
   // (every wave executes these loads -- straight-line code keeps the compiler from copying the
   // loaded registers, and thereby waiting for them, at the end of the front-end branch)
-  uint32_t ie_pref = idx_at(half * 64 + lane);
-  uint32_t io_pref = idx_at((1 - half) * 64 + lane);
-  for (uint32_t k = tid; k <= n_chunks && k < kMaxSteps; k += kD2Threads)
-    s_sbase[k] = k < n_chunks ? idx_at(k * 128) >> 11 : total;
+  uint32_t ie_pref = half * 64 + lane < n_regions ? ie0 : none_end;
+  uint32_t io_pref = (1 - half) * 64 + lane < n_regions ? io0 : none_end;
+  if (tid <= n_chunks && tid < kMaxSteps) s_sbase[tid] = tid < n_chunks ? sb0 >> 11 : total;
   __syncthreads();
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
