@@ -638,6 +638,22 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           if (c < 64) break;
         }
         cbar();
+        // ---- everything the turn needs is worked out before the wait: the four source addresses, where
+        // the dword goes, whether any lane has to store bytewise -- between seeing the frontier and
+        // publishing there are the gather, three instructions of assembly and two stores ----
+        static_assert(B == 4, "one dword per lane");
+        // a dword that is entirely this step's: its other bytes are final (literals) and may be
+        // rewritten with their own value; the step's first and last dwords are stored bytewise
+        // (the front end may be writing the next step's literals into the same dword right now)
+        const bool full = (rmask & 15) == 15;
+        const bool any4 = cp[0] || cp[1] || cp[2] || cp[3];
+        const bool any_partial = ballot(!full && any4) != 0;
+        lds_u8* const wo = (lds_u8*)s_out;
+        uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
+        uint32_t ad = (full && any4) ? p : sink;
+        uint32_t front_after = g + kGroup * (1 + nskip);
+        front_after = front_after < cn ? front_after : cn;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(ad), "+s"(front_after));
         // ---- my turn: every group below mine has published, i.e. everything below g is final ------
         const uint32_t expect = g > cb ? g : cb;
         // (from here to the publish this wave is, or is about to be, on the step's critical path)
@@ -657,29 +673,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         }
         if (work) {
           // every source is final now: gather (most groups would have to fetch again after an early
-          // gather anyway, and the CU is issue-bound, not latency-bound)
-          uint32_t v[B / 4];
+          // gather anyway)
+          const uint32_t v = (uint32_t)wo[a0] | ((uint32_t)wo[a1] << 8) | ((uint32_t)wo[a2] << 16) | ((uint32_t)wo[a3] << 24);
+          *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(wo + ad) = v;
+          if (any_partial) {
 #pragma unroll
-          for (uint32_t k = 0; k < B / 4; k++)
-            v[k] = (uint32_t)s_out[sp[4 * k]] | ((uint32_t)s_out[sp[4 * k + 1]] << 8) |
-                   ((uint32_t)s_out[sp[4 * k + 2]] << 16) | ((uint32_t)s_out[sp[4 * k + 3]] << 24);
-          // a dword that is entirely this step's: its other bytes are final (literals) and may be
-          // rewritten with their own value; the step's first and last dwords are stored bytewise
-          // (the front end may be writing the next step's literals into the same dword right now)
-          bool partial = false;
-#pragma unroll
-          for (uint32_t k = 0; k < B / 4; k++) {
-            const bool full = ((rmask >> (4 * k)) & 15) == 15;
-            const bool any4 = cp[4 * k] || cp[4 * k + 1] || cp[4 * k + 2] || cp[4 * k + 3];
-            *reinterpret_cast<uint32_t*>(s_out + ((full && any4) ? p + 4 * k : sink)) = v[k];
-            partial = partial || (!full && any4);
-          }
-          if (ballot(partial)) {
-#pragma unroll
-            for (uint32_t j = 0; j < B; j++) {
-              const bool full = ((rmask >> (j & ~3u)) & 15) == 15;
-              s_out[(!full && cp[j]) ? p + j : sink + (j & 3)] = (uint8_t)(v[j / 4] >> (8 * (j & 3)));
-            }
+            for (uint32_t j = 0; j < B; j++)
+              wo[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
           }
         }
         if (__builtin_expect(run_end > g + kGroup, 0)) {
@@ -699,10 +699,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
             if (c < 64) break;
           }
           front = run_end + kGroup * nskip;
+          front = front < cn ? front : cn;
         } else {
-          front = g + kGroup * (1 + nskip);
+          front = front_after;
         }
-        front = front < cn ? front : cn;
         cbar();
         if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_s_setprio(0);
