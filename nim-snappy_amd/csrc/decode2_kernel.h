@@ -649,8 +649,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const bool any4 = cp[0] || cp[1] || cp[2] || cp[3];
         const bool any_partial = ballot(!full && any4) != 0;
         lds_u8* const wo = (lds_u8*)s_out;
-        uint32_t a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3];
-        uint32_t ad = (full && any4) ? p : sink;
+        // (complete LDS addresses: the window does not start at LDS address 0)
+        uint32_t a0 = (uint32_t)(uintptr_t)(wo + sp[0]), a1 = (uint32_t)(uintptr_t)(wo + sp[1]);
+        uint32_t a2 = (uint32_t)(uintptr_t)(wo + sp[2]), a3 = (uint32_t)(uintptr_t)(wo + sp[3]);
+        uint32_t ad = (uint32_t)(uintptr_t)(wo + ((full && any4) ? p : sink));
         uint32_t front_after = g + kGroup * (1 + nskip);
         front_after = front_after < cn ? front_after : cn;
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(ad), "+s"(front_after));
@@ -674,8 +676,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         if (work) {
           // every source is final now: gather (most groups would have to fetch again after an early
           // gather anyway)
-          const uint32_t v = (uint32_t)wo[a0] | ((uint32_t)wo[a1] << 8) | ((uint32_t)wo[a2] << 16) | ((uint32_t)wo[a3] << 24);
-          *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(wo + ad) = v;
+          auto at = [](uint32_t a) { return (const lds_u8*)(uintptr_t)a; };
+          const uint32_t v = (uint32_t)*at(a0) | ((uint32_t)*at(a1) << 8) | ((uint32_t)*at(a2) << 16) | ((uint32_t)*at(a3) << 24);
+          *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)ad = v;
           if (any_partial) {
 #pragma unroll
             for (uint32_t j = 0; j < B; j++)
