@@ -514,11 +514,18 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       constexpr uint32_t B = kGroup / 64;  // bytes per lane (4 or 8): one or two aligned dwords
       // (an empty step has nothing to resolve -- and after a fast-forward its list is not even its own)
       for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn && cb < cn; g += kD2Pool * kGroup) {
-        const uint32_t ge = g > cb ? readfirst((uint32_t)s_gidx[g / kGroup]) : 0;
+        // (one round trip for the three words a group starts with: who covers its first byte, whether
+        // the group behind it is inside a long literal, how far the frontier is)
+        const uint32_t ge_raw = s_gidx[g / kGroup];
+        const uint32_t gn_raw = s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
+        const uint32_t fr_raw = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cbar();
+        const uint32_t ge = g > cb ? readfirst(ge_raw) : 0;
+        const uint32_t gnext = readfirst(gn_raw);
         if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
         const uint32_t p = g + B * lane;
-        front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        front = readfirst(fr_raw);
         if (front > (g > cb ? g : cb)) continue;  // a run extension (below) has covered my group
         // the element that covers byte g is E0 (none in the step's first group when it starts
         // inside it)
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         // how many of the groups after mine are skipped: I publish them with mine
         uint32_t nskip = 0;
         // (only looked into when the next group starts inside a long literal)
-        while (g + kGroup < cn && (readfirst((uint32_t)s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)]) & 0x8000u)) {
+        while (g + kGroup < cn && (gnext & 0x8000u)) {
           const uint32_t gg = g + kGroup * (1 + nskip + lane);
           const uint64_t sk = ballot(gg < cn && is_skip(gg));
           const uint32_t c = (~sk) ? ctz64(~sk) : 64;
