@@ -307,6 +307,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         const uint32_t e = s_lut[tag];
         uint32_t L = e & 127, size = (e >> 7) & 127;
         bool ok = kInterior || (inside && p + size <= n);  // every short form: the element must end inside the stream
+        // what the entry of an element that leaves the region looks like: the short forms (at most 65
+        // bytes) exit at nx itself, with their own length and a size that fits a byte
+        uint32_t nx = (uint32_t)k + size;
+        uint32_t out_code = nx, Ls = L, szb = size;
         if (ballot(inside && (e >> 14))) {  // a literal with length bytes somewhere (rare in text)
           const uint32_t rem = inside ? n - p - 1 : 0;
           const uint32_t lenlen = (tag >> 2) - 59;  // 1..4 where it applies
@@ -317,22 +321,24 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
           L = ll ? llen : L;
           size = ll ? 1 + lenlen + llen : size;
           ok = ll ? lok : ok;
+          nx = (uint32_t)k + size;  // ok => no wrap
+          // (only such a literal can exit far away; with the number of its length bytes in the exit code
+          // and its length in the entry itself the chain step needs no second look at the stream)
+          const uint32_t far_code = kExitFar + ((((tag >> 2) - 60) & 3) << 5) + (uint32_t)k;
+          out_code = nx < kExitFar ? nx : far_code;
+          Ls = L < kOutSat ? L : kOutSat;
+          szb = size < 255 ? size : 255;
         }
-        const uint32_t Ls = L < kOutSat ? L : kOutSat;
-        const uint32_t nx = (uint32_t)k + size;  // ok => no wrap
         const bool inreg = ok && nx < kRegion;
         const uint32_t tn = s_tab[row + (inreg ? nx : (uint32_t)k)];
         // the fields are additive along the chain: same exit, one more element, L more bytes
         // (an error or end entry keeps its exit code; in-region lengths are <= 64, so the 17-bit
         // sum cannot overflow past the saturated terminal element)
         const uint32_t t_in = tn + ((1u << 10) | (L << 15));
-        // (only a literal with length bytes can reach that far; with their number in the exit code
-        // and its length in the entry itself the chain step needs no second look at the stream)
-        const uint32_t far_code = kExitFar + ((((tag >> 2) - 60) & 3) << 5) + (uint32_t)k;
-        const uint32_t t_out_of = (nx < kExitFar ? nx : far_code) | (1u << 10) | (Ls << 15);
+        const uint32_t t_out_of = out_code | (1u << 10) | (Ls << 15);
         const uint32_t t = !inside ? t_pack(kExitEnd, 0, 0)
                                    : (!ok ? t_pack(kExitErr, 0, 0) : (inreg ? t_in : t_out_of));
-        const uint32_t szb = ok ? (size < 255 ? size : 255) : 255;
+        szb = ok ? szb : 255;
         s_tab[row + k] = t;
         s_sz[row8 + k] = (uint8_t)szb;
       }
