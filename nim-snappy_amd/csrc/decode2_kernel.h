@@ -18,12 +18,17 @@
 //           recorded which element covers each 256-byte boundary); a copy byte's source is "own
 //           position - offset".  Sources inside the group are followed to a byte that is final
 //           (pointer doubling, a few rounds through a 512-byte scratch); sources below the group
-//           are final once the groups that hold them are done (every wave publishes how many
-//           of its groups it has finished).  The cost does not depend on how long or how deep the
-//           copy chains of the data are.
-//   all     flush the finished block with 16-byte stores.
+//           are final once every group below has published (one frontier, strictly in order): a
+//           wave prepares its group ahead of time and gathers, stores and publishes in its turn.
+//           The cost does not depend on how long or how deep the copy chains of the data are.
+//   all     flush the finished block with 16-byte stores, and -- when the caller wants it -- compute
+//           its masked CRC32C from the window.
 //
 // One workgroup barrier per step separates "list k is complete" from "list k is consumed".
+// What bounds a step is two chains of dependent LDS round trips side by side (the front end's trips,
+// the resolvers' preparations and turns), not instruction issue or LDS bandwidth; their instructions
+// run at raised wave priority.  A unit that is one literal is copied HBM to HBM and never gets here.
+// Workgroup i takes unit order[i] (units of similar compressed length run next to each other).
 //
 // The inner loops are written branch-free: a lane that has nothing to store stores to a sink
 // slot instead of branching around the store (a taken branch costs more than the store).
