@@ -19,8 +19,13 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU."""
+def build(force=False, verbose=False, debug=False):
+    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU.
+
+    debug=True (or SNAPPY_HIP_BUILD_DEBUG=1 at build time) adds -DSNAPPY_HIP_DEBUG: only such a
+    build reads the SNAPPY_HIP_* debug knobs and carries the kernels' phase-ablation / cycle-counter
+    code.  The default library has neither."""
+    debug = debug or os.environ.get("SNAPPY_HIP_BUILD_DEBUG") == "1"
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -28,6 +33,8 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function", "-o", tmp, os.path.join(CSRC, "snappy_hip.hip"),
            "-Wl,-rpath,/opt/rocm/lib"]
+    if debug:
+        cmd.insert(1, "-DSNAPPY_HIP_DEBUG")
     if verbose:
         print(" ".join(cmd))
     try:
@@ -40,4 +47,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, debug="--debug" in sys.argv))

@@ -25,6 +25,17 @@ constexpr uint32_t kNeedsOnePass = 0x80000001u;
 
 enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
 
+// Phase ablation (`dbg`) and cycle counters (`stats`) exist only in builds with -DSNAPPY_HIP_DEBUG
+// (python nim-snappy_amd/build.py --debug): the shipped library has neither, whatever the
+// environment says.
+#ifdef SNAPPY_HIP_DEBUG
+#define SNAPPY_DBG(prm) ((prm).dbg)
+#define SNAPPY_STATS(prm) ((prm).stats)
+#else
+#define SNAPPY_DBG(prm) 0u
+#define SNAPPY_STATS(prm) ((unsigned long long*)nullptr)
+#endif
+
 // ---- wave64 helpers --------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     const uint32_t tag = tb[0];
     const uint32_t hi6 = tag >> 2;
     const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
-    if ((tag & 3) == 0 && 1 + lenlen <= n && !(prm.dbg & 64)) {
+    if ((tag & 3) == 0 && 1 + lenlen <= n && !(SNAPPY_DBG(prm) & 64)) {
       uint32_t L = hi6 + 1;
       if (lenlen) {
         const uint32_t b = tb[1] | (tb[2] << 8) | (tb[3] << 16) | (tb[4] << 24);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         __syncthreads();
       }
     }
-    const unsigned long long tm0 = prm.stats ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long tm0 = SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0;
     // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
     // everything fetched during the previous step is consumed here, BEFORE new loads are issued
     // (the empty asm pins the wait to this point)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       const uint32_t rs = c0 + lane * kSub;
       const uint32_t r_end = rs + kSub < n ? rs + kSub : n;
       uint32_t pos = rs + e_off;
-      bool live = had && pos < n && !(prm.dbg & 4);
+      bool live = had && pos < n && !(SNAPPY_DBG(prm) & 4);
       bool big = false;  // a literal longer than 64 bytes ends my region: done below
       uint32_t big_dst = 0, big_len = 0, big_src = 0, big_slot = 0;
       bool bad = false;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         *(covers ? s_gidx + (mb & (kMaxBlockLen / kGroup - 1)) : sink16) = (uint16_t)slot;
         // ---- literal: payload of up to 8 bytes here, up to 64 in lean_copy's rare loop -----------
         const uint32_t qs = q + hdr;
-        const uint32_t Lw = (lit && L <= 64 && !(prm.dbg & 1)) ? L : 0;  // bytes this lane writes
+        const uint32_t Lw = (lit && L <= 64 && !(SNAPPY_DBG(prm) & 1)) ? L : 0;  // bytes this lane writes
         lean_copy(dst, [&](uint32_t k) { return ring_al(qs + 4 * k); }, qs & 3, Lw);
         if (lit && L > 64) {
           big = true;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       if (ballot(bad) && lane == 0) s_err = 1;
       __builtin_amdgcn_s_setprio(0);
       acc_b += 1;
-    } else if (!fe && s >= 1 && !(prm.dbg & 2)) {
+    } else if (!fe && s >= 1 && !(SNAPPY_DBG(prm) & 2)) {
       // =================================== resolvers ===============================================
       const uint32_t buf = (s - 1) & 1;
       const uint32_t cb = readfirst(s_sbase[s - 1]), cn = readfirst(s_sbase[s]);
@@ -723,16 +723,16 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         __builtin_amdgcn_s_setprio(0);
       }
     }
-    const unsigned long long tm1 = prm.stats ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long tm1 = SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0;
     // Workgroup barrier for LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait
     // for the global prefetches that are meant to stay in flight across the barrier.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (prm.stats) {
+    if (SNAPPY_STATS(prm)) {
       tm_work += tm1 - tm0;
       tm_bar += __builtin_amdgcn_s_memtime() - tm1;
     }
   }
-  if (prm.stats && lane == 0 && (wave == 0 || wave == 2)) {  // DEBUG
+  if (SNAPPY_STATS(prm) && lane == 0 && (wave == 0 || wave == 2)) {  // DEBUG
     unsigned long long* st = prm.stats + (wave == 0 ? 0 : 8);
     atomicAdd(&st[0], (unsigned long long)acc_a);
     atomicAdd(&st[1], (unsigned long long)acc_b);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     if (tid == 0) prm.status[u] = (s_err & 1) ? kInvalidInput : kNeedsOnePass;
     return;
   }
-  if (prm.dbg & 8) return;
+  if (SNAPPY_DBG(prm) & 8) return;
   if (((uintptr_t)gout & 15) == 0) {
     for (uint32_t i = tid * 16; i < total; i += kD2Threads * 16) {
       if (i + 16 <= total) {

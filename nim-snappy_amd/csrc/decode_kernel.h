@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     const uint64_t op_next = (uint64_t)__shfl((uint32_t)(dst - op), last, 64) + op + readlane(L, last);
 
     // ---- literals: no dependencies ----------------------------------------------------------
-    if (!(prm.dbg & 1)) {
+    if (!(SNAPPY_DBG(prm) & 1)) {
       const bool lit = mine && !is_copy;
       if (lit && L <= 16) {  // one element per lane, source in the ring
         const uint64_t qs = (uint64_t)srcv + shift;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     out_fence();
 
     // ---- copies: rounds against the high-water mark ----------------------------------------
-    if (!(prm.dbg & 2)) {
+    if (!(SNAPPY_DBG(prm) & 2)) {
       uint64_t pending = ballot(mine && is_copy);
       const uint64_t src = dst - srcv;  // valid for copy lanes (offset <= dst checked above)
       while (pending) {
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
   }
 
   // ---- flush the finished block to HBM, 16 bytes per lane -----------------------------------
-  if (!OUT_GLOBAL && !(prm.dbg & 4)) {
+  if (!OUT_GLOBAL && !(SNAPPY_DBG(prm) & 4)) {
     wave_fence();
     const uint32_t total = (uint32_t)op;
     if (((uintptr_t)gout & 15) == 0) {  // block-aligned output (the batch layouts): b128 both sides

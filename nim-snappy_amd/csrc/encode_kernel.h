@@ -33,6 +33,7 @@ namespace snappy_hip {
 
 constexpr uint32_t kSeqLen = 320;  // probe-sequence entries (offset passes 65536 at ~250)
 constexpr uint32_t kObSize = 4096; // staging bytes
+constexpr uint32_t kObFlushAt = 3000;  // drain() flushes above this fill; one of its steps adds <= 1 027 bytes
 constexpr uint32_t kObCap = kObSize + 3 * 64 + 16;
 constexpr uint32_t kWinSize = 2304;  // bytes of input around the scan position kept in LDS
 
@@ -114,134 +115,167 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     return q >= wq && (q + bytes <= wend || wend == q_end);  // (the block's end is always "inside")
   };
 
-  auto flush = [&]() {
-    wave_fence();
-    for (uint32_t i = lane * 4; i < ofill; i += 256) {
-      if (i + 4 <= ofill) {
-        st32u(gout + gpos + i, *reinterpret_cast<const uint32_t*>(s_ob + i));
-      } else {
-        for (uint32_t k = i; k < ofill; k++) gout[gpos + k] = s_ob[k];
-      }
-    }
-    gpos += ofill;
-    ofill = 0;
-    wave_fence();
-  };
-  auto reserve = [&](uint32_t bytes) {
-    if (ofill + bytes > kObSize) flush();
-  };
-
-  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
-  auto emit_literal = [&](uint32_t from, uint32_t len) {
-    if (len <= 60 && in_window(from, len)) {  // the common case: one tag byte, payload from the window
-      reserve(61);
-      if (lane < len) s_ob[ofill + 1 + lane] = s_win[from + shift - wq + lane];
-      if (lane == 0) s_ob[ofill] = (uint8_t)((len - 1) << 2);
-      ofill += 1 + len;
-      return;
-    }
-    const uint32_t m = len - 1;
-    const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
-    reserve(w + (len <= 1024 ? len : 0));
-    if (lane == 0) {
-      if (m < 60) {
-        s_ob[ofill] = (uint8_t)(m << 2);
-      } else if (m < 256) {
-        s_ob[ofill] = 60 << 2;
-        s_ob[ofill + 1] = (uint8_t)m;
-      } else {
-        s_ob[ofill] = 61 << 2;
-        s_ob[ofill + 1] = (uint8_t)m;
-        s_ob[ofill + 2] = (uint8_t)(m >> 8);
-      }
-    }
-    ofill += w;
-    if (len <= 64 && in_window(from, len)) {  // the common case: straight from the window
-      if (lane < len) s_ob[ofill + lane] = s_win[from + shift - wq + lane];
-      ofill += len;
-    } else if (len <= 1024) {
-      for (uint32_t i = lane * 4; i < len; i += 256) {
-        if (i + 4 <= len) {
-          st32u(s_ob + ofill + i, ld32u(in + from + i));
-        } else {
-          for (uint32_t k = i; k < len; k++) s_ob[ofill + k] = in[from + k];
+  // ---- output: elements collect in s_ob and leave with wide stores ----------------------------
+  // Everything that is written goes through drain() below, which has the one flush in the kernel.
+  bool finished = false;                // the parse is over; what is pending is all that is left
+  // pending output, written in this order:
+  bool dpend = false;                   // (1) the elements of a fresh round (position-parallel)
+  uint64_t dp_ms = 0, dp_cover = 0;     //     lanes where a copy starts / lanes covered by copies
+  uint32_t dp_lo = 0, dp_hi = 0;        //     literal bytes lie in lanes [lo, hi) outside the copies
+  uint32_t dp_len = 0, dp_off = 0, dp_byte = 0;  // per lane: copy length, copy offset, the byte at the lane's position
+  uint32_t lit_from = 0, lit_len = 0;   // (2) one literal ...
+  uint32_t cp_off = 0, cp_len = 0;      // (3) ... one copy ...
+  uint32_t lit2_from = 0, lit2_len = 0; // (4) ... and the block's final literal (encoder.nim:249-253)
+  auto drain = [&]() {
+    bool want_flush = false;
+    for (;;) {
+      if (want_flush || ofill > kObFlushAt) {  // (a step below adds at most 1 027 bytes)
+        wave_fence();
+        for (uint32_t i = lane * 4; i < ofill; i += 256) {
+          if (i + 4 <= ofill) {
+            st32u(gout + gpos + i, *reinterpret_cast<const uint32_t*>(s_ob + i));
+          } else {
+            for (uint32_t k = i; k < ofill; k++) gout[gpos + k] = s_ob[k];
+          }
         }
+        gpos += ofill;
+        ofill = 0;
+        want_flush = false;
+        wave_fence();
       }
-      ofill += len;
-    } else {  // long literal: HBM -> HBM
-      flush();
-      for (uint32_t i = lane * 4; i < len; i += 256) {
-        if (i + 4 <= len) {
-          st32u(gout + gpos + i, ld32u(in + from + i));
-        } else {
-          for (uint32_t k = i; k < len; k++) gout[gpos + k] = in[from + k];
+      if (dpend) {
+        // One prefix sum places every element of the round: a lane holding a literal byte writes
+        // it (the first lane of a run also the tag, emitLiteral encoder.nim:44-73: runs are <= 63
+        // bytes), a lane where a copy starts writes the copy (emitCopy :81-125, length < 68).
+        dpend = false;
+        const bool lit = lane >= dp_lo && lane < dp_hi && !((dp_cover >> lane) & 1);
+        const uint64_t LIT = ballot(lit);
+        const bool run_start = lit && !(lane > 0 && ((LIT >> (lane - 1)) & 1));
+        const uint32_t rl = ctz64(~(LIT >> lane));  // literal bytes from here to the next copy
+        const uint32_t tagl = rl <= 60 ? 1 : 2;
+        const bool is_copy = (dp_ms >> lane) & 1;
+        const uint32_t length = dp_len, offset = dp_off;
+        const bool two = length > 64;                      // :105-112
+        const uint32_t r = two ? length - 60 : length;     // 4..64
+        const bool c2 = r >= 12 || offset >= 2048;         // :114-125
+        const uint32_t lo8 = offset & 255, hi8 = offset >> 8;
+        const uint32_t last = c2 ? ((((r - 1) << 2) | 2) | (lo8 << 8) | (hi8 << 16))
+                                 : (((hi8 << 5) | ((r - 4) << 2) | 1) | (lo8 << 8));
+        const uint32_t firstw = ((59u << 2) | 2) | (lo8 << 8) | (hi8 << 16);
+        const unsigned long long cbytes = two ? ((unsigned long long)firstw | ((unsigned long long)last << 24))
+                                              : (unsigned long long)last;
+        const uint32_t ctotal = (two ? 3 : 0) + (c2 ? 3 : 2);
+        const uint32_t nb = lit ? 1 + (run_start ? tagl : 0) : (is_copy ? ctotal : 0);
+        uint32_t total;
+        const uint32_t at = ofill + wave_excl_scan(nb, lane, &total);
+        if (lit) {
+          uint32_t o = at;
+          if (run_start) {
+            s_ob[o] = (uint8_t)(rl <= 60 ? (rl - 1) << 2 : 60 << 2);
+            if (tagl == 2) s_ob[o + 1] = (uint8_t)(rl - 1);
+            o += tagl;
+          }
+          s_ob[o] = (uint8_t)dp_byte;
+        } else if (is_copy) {
+          for (uint32_t k = 0; k < ctotal; k++) s_ob[at + k] = (uint8_t)(cbytes >> (8 * k));
         }
+        ofill += total;
+        continue;
       }
-      gpos += len;
+      if (lit_len) {  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
+        const uint32_t from = lit_from, len = lit_len;
+        if (len > 1024 && ofill) {  // a long literal goes from HBM to HBM, behind what is waiting
+          want_flush = true;
+          continue;
+        }
+        lit_len = 0;
+        const uint32_t m = len - 1;
+        const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
+        const uint32_t t0 = m < 60 ? (m << 2) : (m < 256 ? (60u << 2) : (61u << 2));
+        const uint32_t tag = t0 | ((m & 255) << 8) | ((m >> 8) << 16);
+        if (len <= 1024) {
+          if (lane < w) s_ob[ofill + lane] = (uint8_t)(tag >> (8 * lane));
+          ofill += w;
+          if (len <= 64 && in_window(from, len)) {  // the common case: straight from the window
+            if (lane < len) s_ob[ofill + lane] = s_win[from + shift - wq + lane];
+          } else {
+            for (uint32_t i = lane * 4; i < len; i += 256) {
+              if (i + 4 <= len) {
+                st32u(s_ob + ofill + i, ld32u(in + from + i));
+              } else {
+                for (uint32_t k = i; k < len; k++) s_ob[ofill + k] = in[from + k];
+              }
+            }
+          }
+          ofill += len;
+        } else {
+          if (lane < w) gout[gpos + lane] = (uint8_t)(tag >> (8 * lane));
+          gpos += w;
+          for (uint32_t i = lane * 4; i < len; i += 256) {
+            if (i + 4 <= len) {
+              st32u(gout + gpos + i, ld32u(in + from + i));
+            } else {
+              for (uint32_t k = i; k < len; k++) gout[gpos + k] = in[from + k];
+            }
+          }
+          gpos += len;
+        }
+        continue;
+      }
+      if (cp_len) {  // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
+        const uint32_t offset = cp_off, length = cp_len;
+        if (length >= 68) {  // :97-103, up to 64 elements of 64 bytes per step
+          const uint32_t k64 = (length - 68) / 64 + 1;
+          const uint32_t c = k64 < 64 ? k64 : 64;
+          if (lane < c) {
+            s_ob[ofill + 3 * lane] = (63 << 2) | 2;
+            s_ob[ofill + 3 * lane + 1] = (uint8_t)offset;
+            s_ob[ofill + 3 * lane + 2] = (uint8_t)(offset >> 8);
+          }
+          ofill += 3 * c;
+          cp_len = length - 64 * c;
+          continue;
+        }
+        cp_len = 0;
+        const bool two = length > 64;                      // :105-112
+        const uint32_t r = two ? length - 60 : length;     // 4..64
+        const bool c2 = r >= 12 || offset >= 2048;         // :114-125
+        const uint32_t lo8 = offset & 255, hi8 = offset >> 8;
+        const uint32_t last = c2 ? ((((r - 1) << 2) | 2) | (lo8 << 8) | (hi8 << 16))
+                                 : (((hi8 << 5) | ((r - 4) << 2) | 1) | (lo8 << 8));
+        const uint32_t firstw = ((59u << 2) | 2) | (lo8 << 8) | (hi8 << 16);
+        const unsigned long long bytes = two ? ((unsigned long long)firstw | ((unsigned long long)last << 24))
+                                             : (unsigned long long)last;
+        const uint32_t total = (two ? 3 : 0) + (c2 ? 3 : 2);
+        if (lane < total) s_ob[ofill + lane] = (uint8_t)(bytes >> (8 * lane));
+        ofill += total;
+        continue;
+      }
+      if (lit2_len) {
+        lit_from = lit2_from;
+        lit_len = lit2_len;
+        lit2_len = 0;
+        continue;
+      }
+      if (finished && ofill) {
+        want_flush = true;
+        continue;
+      }
+      break;
     }
   };
 
-  // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
-  auto emit_copy = [&](uint32_t offset, uint32_t length) {
-    if (length < 68) {  // the common case, branch-free: at most a 60-byte copy2 + one more element
-      reserve(8);
-      const bool two = length > 64;                      // :105-112
-      const uint32_t r = two ? length - 60 : length;     // 4..64
-      const bool c2 = r >= 12 || offset >= 2048;         // :114-125
-      const uint32_t lo = offset & 255, hi = offset >> 8;
-      const uint32_t last = c2 ? ((((r - 1) << 2) | 2) | (lo << 8) | (hi << 16))
-                               : (((hi << 5) | ((r - 4) << 2) | 1) | (lo << 8));
-      const uint32_t first = ((59u << 2) | 2) | (lo << 8) | (hi << 16);
-      const unsigned long long bytes = two ? ((unsigned long long)first | ((unsigned long long)last << 24))
-                                           : (unsigned long long)last;
-      const uint32_t total = (two ? 3 : 0) + (c2 ? 3 : 2);
-      if (lane < total) s_ob[ofill + lane] = (uint8_t)(bytes >> (8 * lane));
-      ofill += total;
-      return;
-    }
-    uint32_t k64 = length >= 68 ? (length - 68) / 64 + 1 : 0;  // :97-103
-    uint32_t rem = length - 64 * k64;                          // 4..67
-    while (k64) {                                              // <= 64 elements per pass
-      const uint32_t c = k64 < 64 ? k64 : 64;
-      reserve(3 * c);
-      if (lane < c) {
-        s_ob[ofill + 3 * lane] = (63 << 2) | 2;
-        s_ob[ofill + 3 * lane + 1] = (uint8_t)offset;
-        s_ob[ofill + 3 * lane + 2] = (uint8_t)(offset >> 8);
-      }
-      ofill += 3 * c;
-      k64 -= c;
-    }
-    reserve(8);
-    if (lane == 0) {
-      uint32_t o = ofill;
-      if (rem > 64) {  // :105-112
-        s_ob[o] = (59 << 2) | 2;
-        s_ob[o + 1] = (uint8_t)offset;
-        s_ob[o + 2] = (uint8_t)(offset >> 8);
-        o += 3;
-      }
-      const uint32_t r = rem > 64 ? rem - 60 : rem;
-      if (r >= 12 || offset >= 2048) {  // :114-120
-        s_ob[o] = (uint8_t)(((r - 1) << 2) | 2);
-        s_ob[o + 1] = (uint8_t)offset;
-        s_ob[o + 2] = (uint8_t)(offset >> 8);
-      } else {  // :123-125
-        s_ob[o] = (uint8_t)(((offset >> 8) << 5) | ((r - 4) << 2) | 1);
-        s_ob[o + 1] = (uint8_t)offset;
-      }
-    }
-    const uint32_t r = rem > 64 ? rem - 60 : rem;
-    ofill += (rem > 64 ? 3 : 0) + ((r >= 12 || offset >= 2048) ? 3 : 2);
-  };
-
+  // per-block setup (encoder.nim:227-245)
+  uint32_t mask = 0;
+  const uint32_t ip_limit = n >= kInputMargin ? n - kInputMargin : 0;
   if (n < kMinNonLiteral) {  // encoder.nim:227-229
-    if (n) emit_literal(0, n);
+    finished = true;
+    lit2_from = 0;
+    lit2_len = n;
   } else {
-    // ---- per-block setup (encoder.nim:234-245) ---------------------------------------------
     uint32_t table_size = 1u << 8;
     while (table_size < kMaxTableSize && table_size < n) table_size <<= 1;
-    const uint32_t mask = table_size - 1;
+    mask = table_size - 1;
     for (uint32_t i = lane * 8; i < table_size; i += 64 * 8)
       *reinterpret_cast<uint4*>(&s_table[i]) = make_uint4(0, 0, 0, 0);
     for (uint32_t i = lane; i < kSeqLen; i += 64) {
@@ -249,224 +283,443 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       s_seq_off[i] = (uint16_t)(o < 65535 ? o : 65535);
       s_seq_step[i] = (uint16_t)(st < 65535 ? st : 65535);
     }
-    // Lane roles of a round.  After a literal scan that found nothing yet (has0 = false) all 64
-    // lanes are scan probes: lane L probes s0 + off[idx0 + L].  Right after a copy that ended at
-    // ip (has0 = true) lane 0 is the table insert of ip - 1 (encoder.nim:371: a write that is
-    // never a match candidate check), lane 1 the copy-loop probe at ip (:373-380) and lanes 2..63
-    // are the first 62 probes of the scan that starts at ip + 1 -- the order of the lanes is the
-    // order in which the sequential loop touches the table.
-    // The first 64 sequence entries stay in registers in both arrangements (relative to s0 - 2
-    // for has0 rounds, to s0 otherwise); later entries come from LDS.
-    const uint32_t ra_off = prm.seq_off[lane], ra_step = prm.seq_step[lane];
-    const uint32_t rb_off = lane >= 2 ? 2 + prm.seq_off[lane - 2] : lane;
-    const uint32_t rb_step = lane >= 2 ? prm.seq_step[lane - 2] : 0;
-    const uint32_t need0 = readlane(ra_off, 63) + 28;  // bytes after the first lane's position a fresh round may touch
     wave_fence();
-    const uint32_t ip_limit = n - kInputMargin;
     fill_window(0);
+  }
 
-    bool has0 = false;        // lanes 0,1 carry the insert of ip-1 and the copy-loop probe at ip = s0-1
-    uint32_t next_emit = 0;   // start of the pending literal
-    uint32_t s0 = 1;          // position of probe 0 of the current literal scan
-    uint32_t idx0 = 0;        // index into the probe sequence of this round's first scan lane
-    uint32_t tail_from = 0;   // where the final literal starts
+  // Two kinds of round.
+  //
+  // FRESH round (idx0 == 0): lane L <-> position base + L, 64 consecutive positions.  Right after
+  // a copy that ended at ip (has0) base = ip - 1: lane 0 is the table insert of ip - 1
+  // (encoder.nim:371, a write that is never a candidate check), lane 1 the copy-loop probe at ip
+  // (:373-380), lanes 2.. the scan that starts at ip + 1, whose probe offsets from its start are
+  // 0..31, then 32, 34, .. 62 (skip = 32, step = skip >> 5, :311-331 -- the sixteen unrolled
+  // probes :280-309 are its first sixteen).  Every lane hashes ITS position and takes as candidate
+  // the nearest earlier lane with the same slot, else the table value: right if every earlier
+  // lane of the round was inserted.  The chain then walks the round the way the sequential loop
+  // does and, at a match, carries on at the copy's end INSIDE the round (insert, copy-loop probe,
+  // next scan ...).  S collects the lanes the sequential loop really touches; a probe whose
+  // nearest earlier same-slot lane is not in S has seen a candidate the sequential loop would not
+  // have seen, and the round stops in front of it.  At the end the table is left as S alone
+  // leaves it.  A block of text takes about 1 050 such rounds instead of about 10 000 one-match
+  // rounds (tools/encode_model.py is the same procedure on the CPU, checked against the oracle).
+  //
+  // CONTINUING round (idx0 > 0): a scan that found nothing among its first 47 probes; lanes take
+  // the next 64 entries of the probe sequence (positions further and further apart), straight
+  // from memory; one match ends the round.
+  bool has0 = false;        // fresh round after a copy: lanes 0,1 are the insert of ip-1 and the probe at ip = s0-1
+  uint32_t next_emit = 0;   // start of the pending literal
+  uint32_t s0 = 1;          // position of probe 0 of the current literal scan
+  uint32_t idx0 = 0;        // index into the probe sequence of a continuing round's first lane
 
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // DEBUG section timers
-    uint32_t rounds = 0;
-    auto tick = [&](int k) {
-      if (prm.stats) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        tacc[k] += t - tprev;
-        tprev = t;
-      }
-    };
-    if (prm.stats) tprev = __builtin_amdgcn_s_memtime();
-    // The elements of a round are written out during the NEXT round's wait for its candidates
-    // (the one access per round that goes to L2/HBM): emission only needs these four numbers.
-    bool pend = false;
-    uint32_t pend_from = 0, pend_pm = 0, pend_off = 0, pend_len = 0;
-    auto drain = [&]() {
-      if (pend) {
-        if (pend_pm > pend_from) emit_literal(pend_from, pend_pm - pend_from);
-        emit_copy(pend_off, pend_len);
-        pend = false;
-      }
-    };
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // DEBUG section timers
+  uint32_t rounds = 0;
+  auto tick = [&](int k) {
+    if (SNAPPY_STATS(prm)) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tacc[k] += t - tprev;
+      tprev = t;
+    }
+  };
+  if (SNAPPY_STATS(prm)) tprev = __builtin_amdgcn_s_memtime();
+  // findMatchLength beyond what the registers hold, encoder.nim:130-182: exact, bounded by n;
+  // 256 bytes per step across the wave.  a < b are the positions still to compare.
+  auto extend_match = [&](uint32_t a, uint32_t b) -> uint32_t {
+    uint32_t more = 0;
     for (;;) {
-      rounds++;
-      // ---- this round's position per lane, and 16 bytes of input there -------------------------
-      uint32_t p;
-      bool valid;
-      bool pw;  // the 16 bytes at p came from the window (else only pd[0] is loaded)
-      uint32_t pd[4] = {0, 0, 0, 0};
-      const uint32_t first_probe = has0 ? 1 : 0;  // lanes below it only write the table
-      if (idx0 == 0) {
-        // fresh round: everything it touches is in the window
-        const uint32_t base = has0 ? s0 - 2 : s0;
-        if (!in_window(base, need0)) fill_window(base);
-        p = base + (has0 ? rb_off : ra_off);
-        valid = p + (has0 ? rb_step : ra_step) <= ip_limit;  // encoder.nim:318-321 (lanes 0,1: step 0, ip <= ipLimit)
-        pw = valid;
+      const uint32_t pb = b + lane * 4;
+      uint32_t e4 = 0;
+      if (pb < n) {
+        const uint32_t avail = n - pb < 4 ? n - pb : 4;
+        const uint32_t sh = 4 - avail;  // keep the dword load inside the block
+        uint32_t x = (ld32u(in + a + lane * 4 - sh) ^ ld32u(in + pb - sh)) >> (8 * sh);
+        e4 = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4;
+        if (e4 > avail) e4 = avail;
+      }
+      const uint64_t mis = ballot(e4 < 4);
+      if (mis) {
+        const uint32_t f = ctz64(mis);
+        return more + 4 * f + readlane(e4, f);
+      }
+      more += 256;
+      a += 256;
+      b += 256;
+    }
+  };
+  constexpr uint64_t kScanPat = 0x55555555FFFFFFFFull;  // offsets of a scan's first 47 probes: 0..31, 32, 34, .. 62
+  while (!finished) {
+    // ---- this round's position per lane, and 16 bytes of input there ---------------------------
+    const bool fresh = idx0 == 0;
+    uint32_t p = 0, d = 0, dep = 64, base = 0;
+    uint32_t pd1 = 0, pd2 = 0, pd3 = 0;
+    bool valid = false;
+    const uint32_t tsink = kMaxTableSize + lane;
+    rounds++;
+    {
+      if (fresh) {
+        // everything a fresh round touches is in the window
+        base = has0 ? s0 - 2 : 0;  // (the block's first round: lane 0 = position 0 is never probed)
+        if (!in_window(base, 96)) fill_window(base);
+        p = base + lane;
+        valid = p <= ip_limit && (has0 || lane > 0);
         const uint32_t qa = valid ? (p + shift - wq) : 0;
         const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
         const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
         const uint32_t sh8 = (qa & 3) * 8;
-        pd[0] = __funnelshift_r(r0, r1, sh8);
-        pd[1] = __funnelshift_r(r1, r2, sh8);
-        pd[2] = __funnelshift_r(r2, r3, sh8);
-        pd[3] = __funnelshift_r(r3, r4, sh8);
+        d = __funnelshift_r(r0, r1, sh8);
+        pd1 = __funnelshift_r(r1, r2, sh8);
+        pd2 = __funnelshift_r(r2, r3, sh8);
+        pd3 = __funnelshift_r(r3, r4, sh8);
       } else {
-        // a long scan, far ahead of the window: straight from memory (never with has0)
+        // a long scan, far ahead of the window: straight from memory
         const uint32_t si = idx0 + lane;
         p = s0;
-        valid = false;
         if (si < kSeqLen) {
           p = s0 + s_seq_off[si];
-          valid = p + s_seq_step[si] <= ip_limit;
+          valid = p + s_seq_step[si] <= ip_limit;  // encoder.nim:318-321
         }
-        pw = false;
-        if (valid) pd[0] = ld32u(in + p);
+        if (valid) d = ld32u(in + p);
       }
-      const uint64_t vmask = ballot(valid);
-      if (vmask == 0) {
-        drain();
-        tail_from = next_emit;
-        break;
-      }
-      const uint32_t d = pd[0];
-      tick(0);  // positions + input bytes
-      const uint32_t h = snappy_hash(d, mask);
-      // (a lane without a position works on its private sink slot instead of being branched around)
-      const uint32_t tsink = kMaxTableSize + lane;
-      const uint32_t ti = valid ? h : tsink;
-      const uint32_t old = s_table[ti];
-      wave_fence();
-      s_table[ti] = (uint16_t)p;
-      wave_fence();
-      const uint32_t chk = s_table[ti];
-      uint64_t losers = ballot(chk != (p & 0xffffu));
-
-      // candidate as the sequential loop would see it: the position of the nearest earlier lane
-      // of this round with my slot, else what the table held
-      uint32_t cand = old;
-      uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
-      const bool any_conflict = losers != 0;
-      while (losers) {  // one pass per colliding slot
-        const uint32_t j = ctz64(losers);
-        const uint32_t hj = readlane(h, j);
-        const uint64_t g = ballot(valid && h == hj);
-        const bool in_g = valid && h == hj;
-        const uint64_t below = g & ((1ull << lane) - 1);
-        const uint32_t pred = below ? 63 - (uint32_t)__builtin_clzll(below) : lane;
-        const uint32_t pp = __shfl(p, pred, 64);
-        if (in_g) {
-          grp = g;
-          if (below) cand = pp;
-        }
-        losers &= ~g;
-      }
-      tick(1);  // table read / write / read back, conflicts
-
-      // the candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of
-      // encoder.nim:326 and, for window probes, the first 16 bytes of findMatchLength
-      uint4 cv;
-      __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
-      drain();  // the previous round's literal + copy, while the candidates are in flight
-      const uint64_t mm = ballot(valid && lane >= first_probe && cv.x == d);
-      const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vmask);
-      uint32_t eq = 4;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
+    }
+    const uint64_t vmask = ballot(valid);
+    tick(0);  // positions + input bytes
+    if (vmask == 0) {  // (only a continuing round: the scan has reached ipLimit)
+      finished = true;
+      lit2_from = next_emit;
+      lit2_len = n - next_emit;
+      break;
+    }
+    const uint32_t h = snappy_hash(d, mask);
+    // (a lane without a position works on its private sink slot instead of being branched around)
+    const uint32_t ti = valid ? h : tsink;
+    const uint32_t old = s_table[ti];
+    uint4 cv;
+    uint4 cw = make_uint4(0, 0, 0, 0);  // for lanes whose candidate is another lane of the round
+    uint32_t cand = old;
+    uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
+    bool any_conflict;
+    {
       {
-        const uint32_t x1 = pd[1] ^ cv.y, x2 = pd[2] ^ cv.z, x3 = pd[3] ^ cv.w;
-        const uint32_t e3 = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : 16;
-        const uint32_t e2 = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : e3;
-        eq = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : e2;
-        // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
-        eq = eq < n - p ? eq : n - p;
-      }
-      tick(2);  // candidate fetch + compare
-
-      // ---- leave the table as the sequential loop would -------------------------------------
-      if (mm) {
+        // The candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of
+        // encoder.nim:326 and, in fresh rounds, the first 16 bytes of findMatchLength.  This is the
+        // round's one trip to L2/HBM: it leaves as soon as the table has answered, and everything
+        // up to the comparison below (the table write, the lanes that share a slot, the previous
+        // round's output) happens while it is under way.
+        __builtin_memcpy(&cv, in + (valid ? old : 0), 16);
         wave_fence();
-        s_table[(valid && lane > m_eff) ? h : tsink] = (uint16_t)old;  // never executed there
-      }
-      if (any_conflict) {
+        s_table[ti] = (uint16_t)p;
         wave_fence();
-        // of several lanes <= m_eff on one slot the last one wrote last
-        const uint64_t later = lane >= 63 ? 0 : (grp >> (lane + 1));
-        const uint32_t span = m_eff > lane ? m_eff - lane : 0;  // lanes in (lane, m_eff]
-        const uint64_t later_in = span >= 64 ? later : (later & ((1ull << span) - 1));
-        s_table[(valid && lane <= m_eff && later_in == 0) ? h : tsink] = (uint16_t)p;
-      }
-      wave_fence();
+        const uint32_t chk = s_table[ti];
+        uint64_t losers = ballot(chk != (p & 0xffffu));
 
-      if (!mm) {
-        if (vmask == ~0ull) {  // every probe missed: the next entries of the sequence
-          idx0 += has0 ? 62 : 64;
-          has0 = false;
-          continue;
-        }
-        tail_from = next_emit;  // encoder.nim:319-321
-        break;
-      }
-      tick(3);  // table repair
-
-      // ---- literal + copy (encoder.nim:336-359) ---------------------------------------------
-      const uint32_t pm = readlane(p, m_eff);
-      const uint32_t c = readlane(cand, m_eff);
-      tick(4);
-
-      // findMatchLength, encoder.nim:130-182: exact, bounded by n
-      const bool wwide = readlane(pw ? 1u : 0u, m_eff) != 0;
-      uint32_t matched = wwide ? readlane(eq, m_eff) : 4;
-      if (!wwide || (matched == 16 && pm + 16 < n)) {  // longer (or not measured yet): 256 bytes per step
-        uint32_t a = c + matched, b = pm + matched;
-        for (;;) {
-          const uint32_t pb = b + lane * 4;
-          uint32_t e4 = 0;
-          if (pb < n) {
-            const uint32_t avail = n - pb < 4 ? n - pb : 4;
-            const uint32_t sh = 4 - avail;  // keep the dword load inside the block
-            uint32_t x = (ld32u(in + a + lane * 4 - sh) ^ ld32u(in + pb - sh)) >> (8 * sh);
-            e4 = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4;
-            if (e4 > avail) e4 = avail;
+        // candidate as the sequential loop would see it if every earlier lane was inserted: the
+        // position of the nearest earlier lane of this round with my slot, else what the table held
+        any_conflict = losers != 0;
+        while (losers) {  // one pass per colliding slot
+          const uint32_t j = ctz64(losers);
+          const uint32_t hj = readlane(h, j);
+          const uint64_t g = ballot(valid && h == hj);
+          const bool in_g = valid && h == hj;
+          const uint64_t below = g & ((1ull << lane) - 1);
+          const uint32_t pred = below ? 63 - (uint32_t)__builtin_clzll(below) : lane;
+          const uint32_t pp = fresh ? base + pred : __shfl(p, pred, 64);
+          if (in_g) {
+            grp = g;
+            if (below) {
+              cand = pp;
+              dep = pred;  // the nearest earlier lane of my slot
+            }
           }
-          const uint64_t mis = ballot(e4 < 4);
-          if (mis) {
-            const uint32_t f = ctz64(mis);
-            matched += 4 * f + readlane(e4, f);
+          losers &= ~g;
+        }
+        if (any_conflict) {  // lanes whose candidate is another lane of the round: its bytes instead
+          if (fresh) {       // ... which lie in the window (a continuing round stops in front of such a lane)
+            const uint32_t qa = dep < 64 ? (cand + shift - wq) : 0;
+            const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+            const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
+            const uint32_t sh8 = (qa & 3) * 8;
+            cw.x = __funnelshift_r(r0, r1, sh8);
+            cw.y = __funnelshift_r(r1, r2, sh8);
+            cw.z = __funnelshift_r(r2, r3, sh8);
+            cw.w = __funnelshift_r(r3, r4, sh8);
+          }
+        }
+        tick(1);  // table read / write / read back, conflicts
+      }
+    }
+    drain();  // the previous round's elements, while the candidates are in flight
+
+    const bool inr = dep < 64;
+    const uint64_t m4 = ballot(valid && (inr ? cw.x : cv.x) == d);
+    uint32_t eq;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
+    {
+      const uint32_t x1 = pd1 ^ (inr ? cw.y : cv.y), x2 = pd2 ^ (inr ? cw.z : cv.z), x3 = pd3 ^ (inr ? cw.w : cv.w);
+      const uint32_t e3 = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : 16;
+      const uint32_t e2 = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : e3;
+      eq = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : e2;
+      // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
+      eq = eq < n - p ? eq : n - p;
+    }
+    tick(2);  // candidate fetch + compare
+
+    if (fresh) {
+      uint64_t conf = any_conflict ? ballot(dep < 64) : 0;  // lanes whose candidate is another lane of the round
+      uint64_t S = 0, MS = 0, COVER = 0;
+      uint32_t lens = eq;      // per lane: length of the copy that starts here
+      uint32_t e = 1;          // lane of the current copy's end (= ip - base)
+      bool ended = false;      // the block ends inside this round
+      uint32_t tail_from = 0;
+      // state for the next round, set where the chain stops
+      bool n_has0 = true;
+      uint32_t n_s0 = 0, n_idx0 = 0, n_emit = 0;
+      if (has0 && base + 96 <= ip_limit) {
+        // ---- the chain, common case: no lane of the round is near ipLimit ----------------------
+        // (all 64 lanes are valid, every probe of the pattern runs, a copy that ends inside the
+        // round ends at most at ip_limit.)  Every lane works out where the sequential loop would go
+        // if a copy ENDED at it: mv = the first lane that matches among its copy-loop probe and the
+        // probes of the scan behind it, nxt = where that match's copy ends.  The chain itself is
+        // then two register reads per copy.
+        const uint64_t mine = ((kScanPat << 1) | 1ull) << lane;  // (lane 63: the probe at ip alone)
+        const uint64_t cnd = (lane < 63 ? mine : (1ull << 63)) & m4;
+        const uint32_t mv = cnd ? ctz64(cnd) : 64;
+        const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)eq);
+        // 255: nothing found; 128 + m: the match at m is longer than the 16 bytes in registers
+        const uint32_t nxt = mv == 64 ? 255u : (lm == 16 ? 128u + mv : mv + lm);
+        tick(6);
+        uint64_t E = 0;  // ends of copies from which the chain went on
+        uint32_t t = readlane(nxt, e);
+        for (;;) {
+          while (t < 63) {  // the copy found from e ends inside the round
+            E |= 1ull << e;
+            MS |= 1ull << readlane(mv, e);
+            e = t;
+            t = readlane(nxt, e);
+          }
+          if (t == 255) break;  // nothing found from e: the round ends there
+          E |= 1ull << e;
+          if (t >= 128) {       // found, and longer than the registers show
+            const uint32_t m = t - 128;
+            const uint32_t matched = 16 + extend_match(readlane(cand, m) + 16, base + m + 16);
+            lens = lane == m ? matched : lens;
+            MS |= 1ull << m;
+            e = m + matched;
+          } else {              // found, and it ends behind the round
+            MS |= 1ull << readlane(mv, e);
+            e = t;
+          }
+          if (e > 62) break;
+          t = readlane(nxt, e);
+        }
+        tick(7);
+        if (MS) {
+          // What the sequential loop inserted, from the copies' ends: ce = the end of the last copy
+          // that starts in front of a lane (1 for the copy this round started behind).  A lane
+          // behind that end is the copy-loop probe (== ce) or a scan probe by the pattern; a lane
+          // in front of it lies inside the copy, and only its last byte is inserted (ip - 1,
+          // encoder.nim:371).  Nothing behind the last match was touched.
+          const uint32_t endv = ((MS >> lane) & 1) ? lane + lens : 0;
+          uint32_t unused;
+          uint32_t ce = wave_excl_scan_max(endv, lane, &unused);
+          ce = ce > 1 ? ce : 1;
+          COVER = ballot(lane < (ce > endv ? ce : endv));
+          uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
+          const bool in_s = lane >= ce ? (lane == ce || ((kScanPat >> ((lane - ce - 1) & 63)) & 1)) : lane + 1 == ce;
+          S = ballot(in_s) & ((2ull << mlast) - 1);
+          if (conf) {
+            // a probe whose nearest earlier same-slot lane was not inserted saw a wrong candidate:
+            // everything from the copy end in front of the first such probe is undone
+            const uint64_t bad = ballot(dep < 64 && !((S >> (dep & 63)) & 1)) & S & ~(E >> 1);
+            if (bad) {
+              const uint32_t fb = ctz64(bad);
+              const uint64_t eb = E & ((2ull << fb) - 1);
+              e = 63 - (uint32_t)__builtin_clzll(eb);  // (lane 1 is in E: eb != 0)
+              const uint64_t keep = (1ull << e) - 1;
+              MS &= keep;
+              COVER &= keep;
+              S &= keep >> 1;
+            }
+          }
+          if (MS) {
+            n_has0 = true, n_s0 = base + e + 1, n_idx0 = 0, n_emit = base + e;
+            if (base + e > ip_limit) {  // encoder.nim:362 -- strictly greater (only after a long copy)
+              ended = true;
+              tail_from = base + e;
+            }
+          }
+        }
+      }
+      if (MS == 0) {
+        // ---- the chain, every case (the block's first round, rounds near ipLimit, a first
+        // segment that finds nothing or runs into a wrong candidate) ---------------------------
+        const uint64_t L1 = ballot(valid && p + 1 <= ip_limit);  // a step-1 probe runs here (encoder.nim:318-321)
+        const uint64_t L2 = ballot(valid && p + 2 <= ip_limit);  // a step-2 probe runs here
+        bool first = true;  // the round's first segment: it always makes progress
+        S = 0;
+        e = 1;
+        for (;;) {
+          const bool ops = has0 || !first;
+          uint64_t opA = 0, opB = 0;
+          uint32_t ls = 1;
+          if (ops) {
+            if (e > 62) {  // the copy ended outside the round: next round starts there
+              n_has0 = true, n_s0 = base + e + 1, n_idx0 = 0, n_emit = base + e;
+              break;
+            }
+            opA = 1ull << (e - 1);
+            opB = 1ull << e;
+            ls = e + 1;
+          }
+          const uint64_t probes = kScanPat << ls;
+          const uint64_t VS = ((0xFFFFFFFFull << ls) & L1) | ((0x5555555500000000ull << ls) & L2);
+          const uint64_t pmm = (opB | VS) & m4;
+          uint64_t bad = 0;
+          if (conf) {
+            const uint64_t T = S | opA | opB | VS;
+            bad = ballot(dep < 64 && !((T >> (dep & 63)) & 1)) & (opB | VS);
+          }
+          const uint32_t m = pmm ? ctz64(pmm) : 64;
+          const uint32_t fb = bad ? ctz64(bad) : 64;
+          if (fb < 64 && fb <= m) {  // a probe that saw a wrong candidate comes first
+            if (first) {             // keep what lies in front of it, go on from there as a continuing scan
+              const uint64_t below = (1ull << fb) - 1;
+              S |= (opA | opB | VS) & below;
+              n_has0 = false, n_s0 = s0, n_idx0 = (uint32_t)__builtin_popcountll(VS & below), n_emit = next_emit;
+            } else {                 // undo this segment: a fresh round from the last copy's end
+              n_has0 = true, n_s0 = base + e + 1, n_idx0 = 0, n_emit = base + e;
+            }
             break;
           }
-          matched += 256;
-          a += 256;
-          b += 256;
+          if (m == 64) {  // nothing found in what is left of the round
+            if (first) {
+              S |= opA | opB | VS;
+              if (probes & ~VS) {  // the scan reaches ipLimit: encoder.nim:319-321
+                ended = true;
+                tail_from = next_emit;
+              } else {
+                n_has0 = false, n_s0 = s0, n_idx0 = (uint32_t)__builtin_popcountll(VS), n_emit = next_emit;
+              }
+            } else {
+              n_has0 = true, n_s0 = base + e + 1, n_idx0 = 0, n_emit = base + e;
+            }
+            break;
+          }
+          // a match at lane m: literal up to it (if any) + copy (encoder.nim:336-359)
+          S |= opA | opB | (VS & ((2ull << m) - 1));
+          uint32_t matched = readlane(eq, m);
+          if (matched == 16 && base + m + 16 < n) matched += extend_match(readlane(cand, m) + 16, base + m + 16);
+          MS |= 1ull << m;
+          lens = lane == m ? matched : lens;
+          COVER |= (matched >= 64 ? ~0ull : ((1ull << matched) - 1)) << m;
+          e = m + matched;
+          first = false;
+          if (base + e > ip_limit) {  // encoder.nim:362 -- strictly greater
+            ended = true;
+            tail_from = base + e;
+            break;
+          }
         }
       }
-      tick(5);  // match length
-      pend = true;  // literal input[next_emit ..< pm] + copy (pm - c, matched): emitted next round
-      pend_from = next_emit;
-      pend_pm = pm;
-      pend_off = pm - c;
-      pend_len = matched;
-      const uint32_t ip = pm + matched;
-      if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
-        tail_from = ip;
+      tick(3);  // chain
+      // ---- leave the table as the lanes of S alone would have left it --------------------------
+      {
+        wave_fence();
+        const uint64_t gs = grp & S;
+        const uint32_t top = gs ? 63 - (uint32_t)__builtin_clzll(gs) : 64;
+        const bool wr = valid && (gs == 0 || (any_conflict && top == lane));
+        s_table[wr ? h : tsink] = (uint16_t)(gs == 0 ? old : p);
+        wave_fence();
+      }
+      tick(4);  // table repair
+      if (MS) {  // hand the elements over
+        const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
+        const uint32_t llast = readlane(lens, mlast);
+        dpend = true;
+        dp_ms = MS;
+        if (llast >= 68) {  // a long last copy goes the general way
+          dp_ms &= ~(1ull << mlast);
+          cp_off = base + mlast - readlane(cand, mlast);
+          cp_len = llast;
+        }
+        dp_cover = COVER;
+        dp_lo = has0 ? 1 : 0;
+        dp_hi = e < 64 ? e : 64;
+        dp_len = lens;
+        dp_off = p - cand;
+        dp_byte = d & 0xff;
+      }
+      if (ended) {
+        finished = true;
+        lit2_from = tail_from;
+        lit2_len = n - tail_from;  // (may be 0)
         break;
       }
-      // next round: insert of ip - 1 (:371), probe at ip (:373-380), scan from ip + 1
-      has0 = true;
-      s0 = ip + 1;
-      idx0 = 0;
-      next_emit = ip;
+      has0 = n_has0;
+      s0 = n_s0;
+      idx0 = n_idx0;
+      next_emit = n_emit;
+      continue;
     }
-    drain();
-    if (prm.stats && lane == 0) {
-      for (int k = 0; k < 8; k++) atomicAdd(&prm.stats[k], tacc[k]);
-      atomicAdd(&prm.stats[8], (unsigned long long)rounds);
+
+    // ---- continuing round: the first match ends it ---------------------------------------------
+    // A lane that shares its slot with an earlier lane of the round would need that lane's bytes,
+    // which are neither fetched nor in the window: the round is cut in front of the first such lane
+    // (one round in eight of random data; the rest of the scan follows in the next round).
+    const uint64_t confl = any_conflict ? ballot(dep < 64) : 0;
+    const uint32_t cut = confl ? ctz64(confl) : 64;           // >= 1
+    const uint64_t below_cut = confl ? (1ull << cut) - 1 : ~0ull;
+    const uint64_t mm = m4 & below_cut;
+    const uint64_t vm = vmask & below_cut;
+    const uint32_t m_eff = mm ? ctz64(mm) : 63 - (uint32_t)__builtin_clzll(vm);
+    // leave the table as the sequential loop would
+    if (mm || confl) {
+      wave_fence();
+      s_table[(valid && lane > m_eff) ? h : tsink] = (uint16_t)old;  // never executed there
     }
-    if (tail_from < n) emit_literal(tail_from, n - tail_from);  // encoder.nim:249-253
+    if (any_conflict) {
+      wave_fence();
+      // of several lanes <= m_eff on one slot the last one wrote last
+      const uint64_t later = lane >= 63 ? 0 : (grp >> (lane + 1));
+      const uint32_t span = m_eff > lane ? m_eff - lane : 0;  // lanes in (lane, m_eff]
+      const uint64_t later_in = span >= 64 ? later : (later & ((1ull << span) - 1));
+      s_table[(valid && lane <= m_eff && later_in == 0) ? h : tsink] = (uint16_t)p;
+    }
+    wave_fence();
+    if (!mm) {
+      if (vm == below_cut) {  // every probe missed: the next entries of the sequence
+        idx0 += cut;
+        continue;
+      }
+      finished = true;  // encoder.nim:319-321
+      lit2_from = next_emit;
+      lit2_len = n - next_emit;
+      break;
+    }
+    const uint32_t pm = readlane(p, m_eff);
+    const uint32_t c = readlane(cand, m_eff);
+    const uint32_t matched = 4 + extend_match(c + 4, pm + 4);
+    tick(5);  // match length
+    lit_from = next_emit;  // literal input[next_emit ..< pm] + copy (pm - c, matched): emitted next round
+    lit_len = pm - next_emit;
+    cp_off = pm - c;
+    cp_len = matched;
+    const uint32_t ip = pm + matched;
+    if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
+      finished = true;
+      lit2_from = ip;
+      lit2_len = n - ip;
+      break;
+    }
+    // next round: insert of ip - 1 (:371), probe at ip (:373-380), scan from ip + 1
+    has0 = true;
+    s0 = ip + 1;
+    idx0 = 0;
+    next_emit = ip;
   }
-  flush();
+  drain();  // what the last round left, the final literal, the last flush
+  if (SNAPPY_STATS(prm) && lane == 0) {
+    for (int k = 0; k < 8; k++) atomicAdd(&prm.stats[k], tacc[k]);
+    atomicAdd(&prm.stats[8], (unsigned long long)rounds);
+  }
   uint32_t body_len = gpos;
 
   // ---- unit trailer -------------------------------------------------------------------------

@@ -37,6 +37,14 @@ thread_local std::string g_last_error;
     }                                                                                        \
   } while (0)
 
+// Debug knobs (profiles/README.md) are read only by builds with -DSNAPPY_HIP_DEBUG; the shipped
+// library ignores the environment (SNAPPY_HIP_DEVICE, the default context's device, excepted).
+#ifdef SNAPPY_HIP_DEBUG
+inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+inline const char* dbg_env(const char*) { return nullptr; }
+#endif
+
 constexpr uint32_t kSlotStride = 76800;  // >= 8 + 3 + 76490, multiple of 256
 const uint8_t kFramingHeader[10] = {0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59};
 
@@ -356,7 +364,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   p.crc = d_crc;
   p.seq_off = c->d_seq_off;
   p.seq_step = c->d_seq_step;
-  if (nb >= 512 && !getenv("SNAPPY_HIP_NO_ORDER")) {  // launch order: blocks that look alike together
+  if (nb >= 512 && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: blocks that look alike together
     void *d_sk, *d_perm;
     int st = ws_get(c, 16, nb * 8 + kOrderBuckets * 4, &d_sk);
     if (st) return st;
@@ -366,7 +374,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
     p.order = (const uint32_t*)d_perm;
   }
   unsigned long long* d_estats = nullptr;
-  if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+  if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
     HIP_TRY(hipMalloc((void**)&d_estats, 128));
     HIP_TRY(hipMemsetAsync(d_estats, 0, 128, s));
     p.stats = d_estats;
@@ -374,15 +382,15 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   {
     LaunchTimer lt(c, s, 1);
     hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
-                       getenv("SNAPPY_HIP_ENC_LDS") ? atoi(getenv("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
+                       dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
   }
   if (d_estats) {
     unsigned long long h[16];
     HIP_TRY(hipMemcpyAsync(h, d_estats, 128, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double r = h[8] ? (double)h[8] : 1.0;
-    fprintf(stderr, "ENC STATS rounds/block %.0f; ticks per round: probe %.0f table %.0f cand %.0f repair %.0f "
-            "literal %.0f match %.0f copy %.0f insert %.0f\n", r / nb, h[0] / r, h[1] / r, h[2] / r, h[3] / r,
+    fprintf(stderr, "ENC STATS rounds/block %.0f; ticks per round: probe %.0f table %.0f cand+drain %.0f chain-post %.0f "
+            "repair %.0f ext %.0f chain-pre %.0f chain-hops %.0f\n", r / nb, h[0] / r, h[1] / r, h[2] / r, h[3] / r,
             h[4] / r, h[5] / r, h[6] / r, h[7] / r);
     (void)hipFree(d_estats);
   }
@@ -424,8 +432,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   p.kind = d_kind;
   p.n_units = n_units;
   p.unit = unit;
-  if (const char* e = getenv("SNAPPY_HIP_DBG")) p.dbg = atoi(e);
-  const bool v1 = d_kind != nullptr || getenv("SNAPPY_HIP_DECODE_V1") != nullptr;
+  if (const char* e = dbg_env("SNAPPY_HIP_DBG")) p.dbg = atoi(e);
+  const bool v1 = d_kind != nullptr || dbg_env("SNAPPY_HIP_DECODE_V1") != nullptr;
   void* d_done = nullptr;  // per unit: the indexed decode kernel has written its CRC
   if (v1) {
     LaunchTimer lt(c, s, 0);
@@ -475,14 +483,14 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.idx = (const uint32_t*)d_idx;
     dp.n_units = n_units;
     dp.unit = unit;
-    if (const char* e = getenv("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
-    if (n_units >= 512 && !getenv("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
+    if (const char* e = dbg_env("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
+    if (n_units >= 512 && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
       void* d_perm;
       if ((st = launch_order(c, d_in_len, n_units, kOrderByLength, 15, 0, s, &d_perm))) return st;
       ip.order = (const uint32_t*)d_perm;
       dp.order = (const uint32_t*)d_perm;
     }
-    if (d_crc && !getenv("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
+    if (d_crc && !dbg_env("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
       if ((st = ws_get(c, 14, n_units, &d_done))) return st;
       HIP_TRY(hipMemsetAsync(d_done, 0, n_units, s));
       dp.crc = d_crc;
@@ -492,7 +500,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       dp.crc_k32k = c->crc_k32k;
     }
     unsigned long long* d_stats = nullptr;
-    if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+    if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
       HIP_TRY(hipMalloc((void**)&d_stats, 128));
       HIP_TRY(hipMemsetAsync(d_stats, 0, 128, s));
       dp.stats = d_stats;
@@ -501,7 +509,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       LaunchTimer lt(c, s, 4);
       hipLaunchKernelGGL(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
     }
-    if (getenv("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
+    if (dbg_env("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
       uint32_t* d_rep;
       HIP_TRY(hipMalloc((void**)&d_rep, n_units * 16));
       hipLaunchKernelGGL(verify_index_kernel, dim3((uint32_t)((n_units + 63) / 64)), dim3(64), 0, s, ip, d_rep);
@@ -521,7 +529,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     {
       LaunchTimer lt(c, s, 0);
       hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
-                         kOutAlloc + (getenv("SNAPPY_HIP_ONE_WG") ? 8192 : 0) /* DEBUG: one per CU */, s, dp);
+                         kOutAlloc + (dbg_env("SNAPPY_HIP_ONE_WG") ? 8192 : 0) /* DEBUG: one per CU */, s, dp);
     }
     if (d_stats) {
       unsigned long long h[16];
@@ -535,7 +543,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       (void)hipFree(d_stats);
     }
   }
-  if (!v1 && !getenv("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined
+  if (!v1 && !dbg_env("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined
     LaunchTimer lt(c, s, 5);
     p.only_status = kNeedsOnePass;
     hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
@@ -821,7 +829,7 @@ int uncompress_split_host(const uint8_t* in, size_t n, uint32_t hdr, uint64_t le
   ip.unit = kUnitRaw;
   ip.blk_in = (uint32_t*)d_blk;
   unsigned long long* d_sdbg = nullptr;
-  if (getenv("SNAPPY_HIP_STATS")) {  // DEBUG
+  if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
     HIP_TRY(hipMalloc((void**)&d_sdbg, 64));
     HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
     ip.idx = (uint32_t*)d_sdbg;
@@ -985,7 +993,7 @@ extern "C" int snappy_hip_uncompress(const uint8_t* in, size_t n, uint8_t* out, 
   if ((uint64_t)cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
   if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;       // unit lengths are 32-bit
   std::lock_guard<std::mutex> lk(g_mu);
-  if (len > kMaxBlockLen && !getenv("SNAPPY_HIP_NO_SPLIT")) {  // several blocks: split, then decode in parallel
+  if (len > kMaxBlockLen && !dbg_env("SNAPPY_HIP_NO_SPLIT")) {  // several blocks: split, then decode in parallel
     const int rs = uncompress_split_host(in, n, (uint32_t)hdr, len, out, written);
     if (rs >= 0) return rs;
   }

@@ -7,9 +7,10 @@ for d in dirs:
         disp = collections.defaultdict(set)
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "decode_indexed" not in k and "index_units" not in k:
+            names = ("decode_indexed", "index_units", "encode_blocks")
+            if not any(x in k for x in names):
                 continue
-            k = "decode_indexed" if "decode_indexed" in k else "index_units"
+            k = [x for x in names if x in k][0]
             acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
             disp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
         for k, v in acc.items():
