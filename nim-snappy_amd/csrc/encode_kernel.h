@@ -126,7 +126,42 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   uint32_t lit_from = 0, lit_len = 0;   // (2) one literal ...
   uint32_t cp_off = 0, cp_len = 0;      // (3) ... one copy ...
   uint32_t lit2_from = 0, lit2_len = 0; // (4) ... and the block's final literal (encoder.nim:249-253)
+  // The elements of a fresh round.  One prefix sum places them all: a lane holding a literal byte
+  // writes it (the first lane of a run also the tag, emitLiteral encoder.nim:44-73: runs are <= 63
+  // bytes), a lane where a copy starts writes the copy (emitCopy :81-125; lengths <= 64 only, so
+  // one element of 2 or 3 bytes).  No lane writes more than three bytes; a lane with fewer writes
+  // the rest to its sink behind the buffer -- no branches.
+  auto emit_round = [&]() {
+    dpend = false;
+    const uint64_t range = (dp_hi < 64 ? (1ull << dp_hi) - 1 : ~0ull) & ~((1ull << dp_lo) - 1);
+    const uint64_t LIT = ~dp_cover & range;
+    const uint64_t here = LIT >> lane;  // bit 0: this lane, bit k: lane + k
+    const bool lit = here & 1;
+    const bool run_start = lit && !(((LIT << 1) >> lane) & 1);
+    const uint32_t rl = ctz64(~here);   // literal bytes from here to the next copy
+    const bool is_copy = (dp_ms >> lane) & 1;
+    const uint32_t length = dp_len, offset = dp_off;
+    const bool c2 = length >= 12 || offset >= 2048;  // :114-125
+    const uint32_t cval = c2 ? ((((length - 1) << 2) | 2) | (offset << 8))
+                             : ((((offset >> 8) << 5) | ((length - 4) << 2) | 1) | ((offset & 255) << 8));
+    const bool tag2 = rl > 60;
+    const uint32_t lval = !run_start ? dp_byte
+                          : (tag2 ? ((60u << 2) | ((rl - 1) << 8) | (dp_byte << 16)) : (((rl - 1) << 2) | (dp_byte << 8)));
+    const uint32_t val = lit ? lval : cval;
+    const uint32_t nb = lit ? (run_start ? (tag2 ? 3 : 2) : 1) : (is_copy ? (c2 ? 3 : 2) : 0);
+    uint32_t total;
+    const uint32_t at = ofill + wave_excl_scan(nb, lane, &total);
+    const uint32_t sink = kObSize + 64 + lane;
+    s_ob[nb > 0 ? at : sink] = (uint8_t)val;
+    s_ob[nb > 1 ? at + 1 : sink] = (uint8_t)(val >> 8);
+    s_ob[nb > 2 ? at + 2 : sink] = (uint8_t)(val >> 16);
+    ofill += total;
+  };
   auto drain = [&]() {
+    if (dpend && ofill <= kObFlushAt && (lit_len | cp_len | lit2_len) == 0 && !finished) {  // the usual case
+      emit_round();
+      return;
+    }
     bool want_flush = false;
     for (;;) {
       if (want_flush || ofill > kObFlushAt) {  // (a step below adds at most 1 027 bytes)
@@ -144,42 +179,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         wave_fence();
       }
       if (dpend) {
-        // One prefix sum places every element of the round: a lane holding a literal byte writes
-        // it (the first lane of a run also the tag, emitLiteral encoder.nim:44-73: runs are <= 63
-        // bytes), a lane where a copy starts writes the copy (emitCopy :81-125, length < 68).
-        dpend = false;
-        const bool lit = lane >= dp_lo && lane < dp_hi && !((dp_cover >> lane) & 1);
-        const uint64_t LIT = ballot(lit);
-        const bool run_start = lit && !(lane > 0 && ((LIT >> (lane - 1)) & 1));
-        const uint32_t rl = ctz64(~(LIT >> lane));  // literal bytes from here to the next copy
-        const uint32_t tagl = rl <= 60 ? 1 : 2;
-        const bool is_copy = (dp_ms >> lane) & 1;
-        const uint32_t length = dp_len, offset = dp_off;
-        const bool two = length > 64;                      // :105-112
-        const uint32_t r = two ? length - 60 : length;     // 4..64
-        const bool c2 = r >= 12 || offset >= 2048;         // :114-125
-        const uint32_t lo8 = offset & 255, hi8 = offset >> 8;
-        const uint32_t last = c2 ? ((((r - 1) << 2) | 2) | (lo8 << 8) | (hi8 << 16))
-                                 : (((hi8 << 5) | ((r - 4) << 2) | 1) | (lo8 << 8));
-        const uint32_t firstw = ((59u << 2) | 2) | (lo8 << 8) | (hi8 << 16);
-        const unsigned long long cbytes = two ? ((unsigned long long)firstw | ((unsigned long long)last << 24))
-                                              : (unsigned long long)last;
-        const uint32_t ctotal = (two ? 3 : 0) + (c2 ? 3 : 2);
-        const uint32_t nb = lit ? 1 + (run_start ? tagl : 0) : (is_copy ? ctotal : 0);
-        uint32_t total;
-        const uint32_t at = ofill + wave_excl_scan(nb, lane, &total);
-        if (lit) {
-          uint32_t o = at;
-          if (run_start) {
-            s_ob[o] = (uint8_t)(rl <= 60 ? (rl - 1) << 2 : 60 << 2);
-            if (tagl == 2) s_ob[o + 1] = (uint8_t)(rl - 1);
-            o += tagl;
-          }
-          s_ob[o] = (uint8_t)dp_byte;
-        } else if (is_copy) {
-          for (uint32_t k = 0; k < ctotal; k++) s_ob[at + k] = (uint8_t)(cbytes >> (8 * k));
-        }
-        ofill += total;
+        emit_round();
         continue;
       }
       if (lit_len) {  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
@@ -405,7 +405,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         // round's one trip to L2/HBM: it leaves as soon as the table has answered, and everything
         // up to the comparison below (the table write, the lanes that share a slot, the previous
         // round's output) happens while it is under way.
+#ifdef ENC_EARLY_FETCH
         __builtin_memcpy(&cv, in + (valid ? old : 0), 16);
+#endif
         wave_fence();
         s_table[ti] = (uint16_t)p;
         wave_fence();
@@ -432,7 +434,12 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           }
           losers &= ~g;
         }
+#ifndef ENC_EARLY_FETCH
+        __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
+        if (0) {
+#else
         if (any_conflict) {  // lanes whose candidate is another lane of the round: its bytes instead
+#endif
           if (fresh) {       // ... which lie in the window (a continuing round stops in front of such a lane)
             const uint32_t qa = dep < 64 ? (cand + shift - wq) : 0;
             const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
@@ -448,8 +455,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
     }
     drain();  // the previous round's elements, while the candidates are in flight
+    tick(2);  // drain
 
+#ifndef ENC_EARLY_FETCH
+    const bool inr = false;
+#else
     const bool inr = dep < 64;
+#endif
     const uint64_t m4 = ballot(valid && (inr ? cw.x : cv.x) == d);
     uint32_t eq;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
     {
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
       eq = eq < n - p ? eq : n - p;
     }
-    tick(2);  // candidate fetch + compare
+    tick(3);  // wait for the candidates + compare
 
     if (fresh) {
       uint64_t conf = any_conflict ? ballot(dep < 64) : 0;  // lanes whose candidate is another lane of the round
@@ -485,32 +497,51 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)eq);
         // 255: nothing found; 128 + m: the match at m is longer than the 16 bytes in registers
         const uint32_t nxt = mv == 64 ? 255u : (lm == 16 ? 128u + mv : mv + lm);
-        tick(6);
+        const uint32_t pk = nxt | (mv << 8);
+        tick(4);  // chain: per-lane preparation
         uint64_t E = 0;  // ends of copies from which the chain went on
-        uint32_t t = readlane(nxt, e);
+        uint32_t x = readlane(pk, e);
+        uint32_t t = x & 255;
         for (;;) {
-          while (t < 63) {  // the copy found from e ends inside the round
-            E |= 1ull << e;
-            MS |= 1ull << readlane(mv, e);
-            e = t;
-            t = readlane(nxt, e);
+          if (t < 63) {
+            // the copy found from e ends inside the round at t: note e and the match, go to t.
+            // (A taken branch costs a lone wave about 25 cycles, a register read across lanes as
+            // much, a scalar instruction 5: this loop is written out so that a copy costs one of
+            // each and eight scalar instructions.)
+            uint64_t tmp;
+            uint32_t m;
+            asm volatile(
+                "1:\n"
+                "s_lshl_b64 %[tmp], 1, %[e]\n"
+                "s_or_b64 %[E], %[E], %[tmp]\n"
+                "s_lshr_b32 %[m], %[x], 8\n"
+                "s_lshl_b64 %[tmp], 1, %[m]\n"
+                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_mov_b32 %[e], %[t]\n"
+                "v_readlane_b32 %[x], %[pk], %[e]\n"
+                "s_and_b32 %[t], %[x], 0xff\n"
+                "s_cmp_lt_u32 %[t], 63\n"
+                "s_cbranch_scc1 1b\n"
+                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "+s"(t), [x] "+s"(x), [tmp] "=&s"(tmp), [m] "=&s"(m)
+                : [pk] "v"(pk)
+                : "scc");
           }
           if (t == 255) break;  // nothing found from e: the round ends there
           E |= 1ull << e;
+          const uint32_t m = x >> 8;
+          MS |= 1ull << m;
           if (t >= 128) {       // found, and longer than the registers show
-            const uint32_t m = t - 128;
             const uint32_t matched = 16 + extend_match(readlane(cand, m) + 16, base + m + 16);
             lens = lane == m ? matched : lens;
-            MS |= 1ull << m;
             e = m + matched;
           } else {              // found, and it ends behind the round
-            MS |= 1ull << readlane(mv, e);
             e = t;
           }
           if (e > 62) break;
-          t = readlane(nxt, e);
+          x = readlane(pk, e);
+          t = x & 255;
         }
-        tick(7);
+        tick(5);  // chain: hops
         if (MS) {
           // What the sequential loop inserted, from the copies' ends: ce = the end of the last copy
           // that starts in front of a lane (1 for the copy this round started behind).  A lane
@@ -619,7 +650,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           }
         }
       }
-      tick(3);  // chain
+      tick(6);  // chain: S, COVER (and the general chain)
       // ---- leave the table as the lanes of S alone would have left it --------------------------
       {
         wave_fence();
@@ -629,13 +660,12 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         s_table[wr ? h : tsink] = (uint16_t)(gs == 0 ? old : p);
         wave_fence();
       }
-      tick(4);  // table repair
       if (MS) {  // hand the elements over
         const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
         const uint32_t llast = readlane(lens, mlast);
         dpend = true;
         dp_ms = MS;
-        if (llast >= 68) {  // a long last copy goes the general way
+        if (llast > 64) {  // a long last copy goes the general way
           dp_ms &= ~(1ull << mlast);
           cp_off = base + mlast - readlane(cand, mlast);
           cp_len = llast;
@@ -647,6 +677,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         dp_off = p - cand;
         dp_byte = d & 0xff;
       }
+      tick(7);  // table repair, hand-over
       if (ended) {
         finished = true;
         lit2_from = tail_from;
@@ -697,7 +728,6 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     const uint32_t pm = readlane(p, m_eff);
     const uint32_t c = readlane(cand, m_eff);
     const uint32_t matched = 4 + extend_match(c + 4, pm + 4);
-    tick(5);  // match length
     lit_from = next_emit;  // literal input[next_emit ..< pm] + copy (pm - c, matched): emitted next round
     lit_len = pm - next_emit;
     cp_off = pm - c;
