@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   bool finished = false;                // the parse is over; what is pending is all that is left
   // pending output, written in this order:
   bool dpend = false;                   // (1) the elements of a fresh round (position-parallel)
-  uint64_t dp_ms = 0, dp_cover = 0;     //     lanes where a copy starts / lanes covered by copies
-  uint32_t dp_lo = 0, dp_hi = 0;        //     literal bytes lie in lanes [lo, hi) outside the copies
+  uint64_t dp_ms = 0;                   //     lanes where a copy starts
+  bool dp_lit = false;                  //     per lane: its byte is a literal byte
   uint32_t dp_len = 0, dp_off = 0, dp_byte = 0;  // per lane: copy length, copy offset, the byte at the lane's position
   uint32_t lit_from = 0, lit_len = 0;   // (2) one literal ...
   uint32_t cp_off = 0, cp_len = 0;      // (3) ... one copy ...
@@ -133,8 +133,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   // the rest to its sink behind the buffer -- no branches.
   auto emit_round = [&]() {
     dpend = false;
-    const uint64_t range = (dp_hi < 64 ? (1ull << dp_hi) - 1 : ~0ull) & ~((1ull << dp_lo) - 1);
-    const uint64_t LIT = ~dp_cover & range;
+    const uint64_t LIT = ballot(dp_lit);
     const uint64_t here = LIT >> lane;  // bit 0: this lane, bit k: lane + k
     const bool lit = here & 1;
     const bool run_start = lit && !(((LIT << 1) >> lane) & 1);
@@ -347,6 +346,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     }
   };
   constexpr uint64_t kScanPat = 0x55555555FFFFFFFFull;  // offsets of a scan's first 47 probes: 0..31, 32, 34, .. 62
+  // the lanes a copy that ends at THIS lane looks at next: its copy-loop probe, then the scan's probes
+  const uint64_t mine = ((kScanPat << 1) | 1ull) << lane;
   while (!finished) {
     // ---- this round's position per lane, and 16 bytes of input there ---------------------------
     const bool fresh = idx0 == 0;
@@ -412,11 +413,31 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         s_table[ti] = (uint16_t)p;
         wave_fence();
         const uint32_t chk = s_table[ti];
-        uint64_t losers = ballot(chk != (p & 0xffffu));
+        const bool lost = chk != (p & 0xffffu);  // another lane of the round has my slot, and wrote last
+        uint64_t losers = ballot(lost);
 
         // candidate as the sequential loop would see it if every earlier lane was inserted: the
         // position of the nearest earlier lane of this round with my slot, else what the table held
         any_conflict = losers != 0;
+        if (any_conflict && fresh) {
+          // Nearly every shared slot is shared by two lanes: the one that lost writes once more, and
+          // now each of the two reads the other's position (its lane: positions are consecutive).
+          // A lane that loses again is one of three or more on a slot; those go through the loop.
+          wave_fence();
+          s_table[lost ? h : tsink] = (uint16_t)p;
+          wave_fence();
+          const uint32_t chk2 = s_table[ti];
+          const bool lost2 = lost && chk2 != (p & 0xffffu);
+          const uint32_t partner = ((lost ? chk : chk2) - base) & 0xffffu;
+          if (valid && (lost || chk2 != (p & 0xffffu))) {
+            grp |= 1ull << (partner & 63);
+            if (partner < lane) {
+              cand = base + partner;
+              dep = partner;
+            }
+          }
+          losers = ballot(lost2);
+        }
         while (losers) {  // one pass per colliding slot
           const uint32_t j = ctz64(losers);
           const uint32_t hj = readlane(h, j);
@@ -477,6 +498,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     if (fresh) {
       uint64_t conf = any_conflict ? ballot(dep < 64) : 0;  // lanes whose candidate is another lane of the round
       uint64_t S = 0, MS = 0, COVER = 0;
+      bool covered = false;    // per lane: inside a copy of this round
+      bool in_s = false;       // per lane: touched by the sequential loop (its table write stays)
       uint32_t lens = eq;      // per lane: length of the copy that starts here
       uint32_t e = 1;          // lane of the current copy's end (= ip - base)
       bool ended = false;      // the block ends inside this round
@@ -491,8 +514,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         // if a copy ENDED at it: mv = the first lane that matches among its copy-loop probe and the
         // probes of the scan behind it, nxt = where that match's copy ends.  The chain itself is
         // then two register reads per copy.
-        const uint64_t mine = ((kScanPat << 1) | 1ull) << lane;  // (lane 63: the probe at ip alone)
-        const uint64_t cnd = (lane < 63 ? mine : (1ull << 63)) & m4;
+        const uint64_t cnd = mine & m4;
         const uint32_t mv = cnd ? ctz64(cnd) : 64;
         const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)eq);
         // 255: nothing found; 128 + m: the match at m is longer than the 16 bytes in registers
@@ -552,22 +574,22 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           uint32_t unused;
           uint32_t ce = wave_excl_scan_max(endv, lane, &unused);
           ce = ce > 1 ? ce : 1;
-          COVER = ballot(lane < (ce > endv ? ce : endv));
-          uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
-          const bool in_s = lane >= ce ? (lane == ce || ((kScanPat >> ((lane - ce - 1) & 63)) & 1)) : lane + 1 == ce;
-          S = ballot(in_s) & ((2ull << mlast) - 1);
+          covered = lane < (ce > endv ? ce : endv);
+          const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
+          const uint32_t o = lane - ce - 1;  // offset in the scan behind ce (for lanes behind it)
+          in_s = lane <= mlast && (lane >= ce ? (lane == ce || o < 32 || !(o & 1)) : lane + 1 == ce);
           if (conf) {
             // a probe whose nearest earlier same-slot lane was not inserted saw a wrong candidate:
             // everything from the copy end in front of the first such probe is undone
+            S = ballot(in_s);
             const uint64_t bad = ballot(dep < 64 && !((S >> (dep & 63)) & 1)) & S & ~(E >> 1);
             if (bad) {
               const uint32_t fb = ctz64(bad);
               const uint64_t eb = E & ((2ull << fb) - 1);
               e = 63 - (uint32_t)__builtin_clzll(eb);  // (lane 1 is in E: eb != 0)
-              const uint64_t keep = (1ull << e) - 1;
-              MS &= keep;
-              COVER &= keep;
-              S &= keep >> 1;
+              MS &= (1ull << e) - 1;
+              covered = covered && lane < e;
+              in_s = in_s && lane + 1 < e;
             }
           }
           if (MS) {
@@ -649,17 +671,20 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
             break;
           }
         }
+        covered = (COVER >> lane) & 1;
+        in_s = (S >> lane) & 1;
       }
-      tick(6);  // chain: S, COVER (and the general chain)
-      // ---- leave the table as the lanes of S alone would have left it --------------------------
-      {
-        wave_fence();
-        const uint64_t gs = grp & S;
+      tick(6);  // chain: what was inserted, what is covered (and the general chain)
+      // ---- leave the table as the lanes the sequential loop touched would have left it ---------
+      wave_fence();
+      if (!any_conflict) {  // every lane has a slot of its own: the others take their writes back
+        s_table[(valid && !in_s) ? h : tsink] = (uint16_t)old;
+      } else {              // of the lanes on one slot the last one that was touched wrote last
+        const uint64_t gs = grp & ballot(in_s);
         const uint32_t top = gs ? 63 - (uint32_t)__builtin_clzll(gs) : 64;
-        const bool wr = valid && (gs == 0 || (any_conflict && top == lane));
-        s_table[wr ? h : tsink] = (uint16_t)(gs == 0 ? old : p);
-        wave_fence();
+        s_table[(valid && (gs == 0 || top == lane)) ? h : tsink] = (uint16_t)(gs == 0 ? old : p);
       }
+      wave_fence();
       if (MS) {  // hand the elements over
         const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
         const uint32_t llast = readlane(lens, mlast);
@@ -670,9 +695,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           cp_off = base + mlast - readlane(cand, mlast);
           cp_len = llast;
         }
-        dp_cover = COVER;
-        dp_lo = has0 ? 1 : 0;
-        dp_hi = e < 64 ? e : 64;
+        dp_lit = !covered && lane >= (has0 ? 1u : 0u) && lane < e;
         dp_len = lens;
         dp_off = p - cand;
         dp_byte = d & 0xff;
