@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   __shared__ uint32_t s_skip;
   __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup];  // list slot of the element covering byte 256 m
   __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
+  __shared__ uint32_t s_runbad;                          // the unit is not one literal + copies of one offset
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -205,10 +206,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint8_t* in0 = unit + hdr;
   const uint32_t n = n_all - hdr;
 
-  // ---- a unit that is ONE literal (what encodeBlock makes of incompressible data, encoder.nim:249-253):
-  // nothing to resolve, nothing to stage -- the payload goes straight from HBM to HBM. ----------------
+  // ---- the unit's first element, if it is a literal (fb[hdr ..]: the tag and its length bytes;
+  // hdr + 1 + 4 <= 10): lit0_L payload bytes behind lit0_h bytes of tag and length ------------------
+  uint32_t lit0_L = 0, lit0_h = 0;
   {
-    // (fb[hdr ..]: the tag and its length bytes; hdr + 1 + 4 <= 10)
     uint32_t tb[5];
 #pragma unroll
     for (uint32_t k = 0; k < 5; k++) {
@@ -225,31 +226,34 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const uint32_t b = tb[1] | (tb[2] << 8) | (tb[3] << 16) | (tb[4] << 24);
         L = (lenlen == 4 ? b : (b & ((1u << (8 * lenlen)) - 1))) + 1;
       }
-      const uint32_t h = 1 + lenlen;
-      if (L == total && n - h == L) {  // (the index pass has validated the element and the total)
-        const uint8_t* src = in0 + h;
-        if (((uintptr_t)gout & 15) == 0) {
-          for (uint32_t i = tid * 16; i < total; i += kD2Threads * 16) {
-            if (i + 16 <= total) {
-              uint4 v;
-              __builtin_memcpy(&v, src + i, 16);  // (unaligned on the load side, where it is free)
-              *reinterpret_cast<uint4*>(gout + i) = v;
-            } else {
-              for (uint32_t k = i; k < total; k++) gout[k] = src[k];
-            }
-          }
+      lit0_L = L;
+      lit0_h = 1 + lenlen;
+    }
+  }
+  // ---- a unit that is ONE literal (what encodeBlock makes of incompressible data, encoder.nim:249-253):
+  // nothing to resolve, nothing to stage -- the payload goes straight from HBM to HBM. ----------------
+  if (lit0_L == total && n - lit0_h == lit0_L) {  // (the index pass has validated the element and the total)
+    const uint8_t* src = in0 + lit0_h;
+    if (((uintptr_t)gout & 15) == 0) {
+      for (uint32_t i = tid * 16; i < total; i += kD2Threads * 16) {
+        if (i + 16 <= total) {
+          uint4 v;
+          __builtin_memcpy(&v, src + i, 16);  // (unaligned on the load side, where it is free)
+          *reinterpret_cast<uint4*>(gout + i) = v;
         } else {
-          for (uint32_t i = tid * 4; i < total; i += kD2Threads * 4) {
-            if (i + 4 <= total) {
-              st32u(gout + i, ld32u(src + i));
-            } else {
-              for (uint32_t k = i; k < total; k++) gout[k] = src[k];
-            }
-          }
+          for (uint32_t k = i; k < total; k++) gout[k] = src[k];
         }
-        return;  // (no CRC here: crc_done stays 0 and the CRC kernel takes the unit)
+      }
+    } else {
+      for (uint32_t i = tid * 4; i < total; i += kD2Threads * 4) {
+        if (i + 4 <= total) {
+          st32u(gout + i, ld32u(src + i));
+        } else {
+          for (uint32_t k = i; k < total; k++) gout[k] = src[k];
+        }
       }
     }
+    return;  // (no CRC here: crc_done stays 0 and the CRC kernel takes the unit)
   }
 
   const uint32_t shift = shift0 + hdr;  // ring position of the tag stream's first byte (<= 20)
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     s_cnt[1] = 0;
     s_crc_acc = 0;
     s_crc_cnt = 0;
+    s_runbad = 0;
   }
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
@@ -337,6 +342,60 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   uint32_t io_pref = (1 - half) * 64 + lane < n_regions ? io0 : none_end;
   if (tid <= n_chunks && tid < kMaxSteps) s_sbase[tid] = tid < n_chunks ? sb0 >> 11 : total;
   __syncthreads();
+
+  // ---- a unit that is one literal followed by copies that all have ONE offset (what encodeBlock
+  // makes of a period: zeros, a repeating pattern, a ramp -- every match is found at the same
+  // distance and emitCopy cuts it into copy2 elements, encoder.nim:97-120): its output is periodic
+  // behind the literal, out[x] = out[x - offset], so it is written straight to HBM from one image of
+  // the period in LDS.  The whole tag stream is in the ring; the index pass has validated it as a
+  // sequence of elements, so "every third byte behind the literal is a copy2 tag" proves that those
+  // are the element starts.  (decoder.nim:112: 1 <= offset <= the literal's length.)
+  if (lit0_L && lit0_L < total && ((uintptr_t)gout & 15) == 0 && n + shift <= kD2Ring &&
+      lit0_h + lit0_L + 3 <= n && (n - lit0_h - lit0_L) % 3 == 0) {
+    const uint32_t q0 = lit0_h + lit0_L;  // the first copy
+    const uint32_t nrec = (n - q0) / 3;
+    auto rb = [&](uint32_t t) -> uint32_t { return s_ring[t + shift]; };
+    const uint32_t roff = rb(q0 + 1) | (rb(q0 + 2) << 8);
+    if ((rb(q0) & 3) == 2 && roff >= 1 && roff <= lit0_L) {
+      bool okr = true;
+      for (uint32_t k = tid; k < nrec; k += kD2Threads) {
+        const uint32_t t = q0 + 3 * k;
+        okr = okr && (rb(t) & 3) == 2 && (rb(t + 1) | (rb(t + 2) << 8)) == roff;
+      }
+      if (!okr) s_runbad = 1;
+      __syncthreads();
+      if (s_runbad == 0) {
+        // image of the period: rep[i] = out[L - offset + i mod offset] for i < M + 16, M a multiple
+        // of the offset of about 4 KiB
+        const uint32_t M = roff * (4096 / roff > 0 ? 4096 / roff : 1);
+        const uint32_t pb = lit0_h + lit0_L - roff;  // stream position of the period's first byte
+        for (uint32_t i0 = tid * 16; i0 < M + 16; i0 += kD2Threads * 16) {
+          uint32_t r = i0 % roff;
+#pragma unroll
+          for (uint32_t j = 0; j < 16; j++) {
+            s_out[i0 + j] = (uint8_t)rb(pb + r);
+            r = r + 1 == roff ? 0 : r + 1;
+          }
+        }
+        __syncthreads();
+        const uint32_t* const rep32 = reinterpret_cast<const uint32_t*>(s_out);
+        for (uint32_t x = tid * 16; x < total; x += kD2Threads * 16) {
+          if (x >= lit0_L && x + 16 <= total) {
+            const uint32_t ix = (x - lit0_L) % M;
+            const uint32_t a = ix >> 2, sh8 = (ix & 3) * 8;
+            const uint32_t r0 = rep32[a], r1 = rep32[a + 1], r2 = rep32[a + 2], r3 = rep32[a + 3], r4 = rep32[a + 4];
+            *reinterpret_cast<uint4*>(gout + x) =
+                make_uint4(__funnelshift_r(r0, r1, sh8), __funnelshift_r(r1, r2, sh8), __funnelshift_r(r2, r3, sh8),
+                           __funnelshift_r(r3, r4, sh8));
+          } else {
+            for (uint32_t k = x; k < x + 16 && k < total; k++)
+              gout[k] = k < lit0_L ? (uint8_t)rb(lit0_h + k) : s_out[(k - lit0_L) % M];
+          }
+        }
+        return;  // (no CRC here: crc_done stays 0 and the CRC kernel takes the unit)
+      }
+    }
+  }
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
 

@@ -79,6 +79,22 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// Makes a context's device current for one call and gives the caller's device back afterwards (a
+// thread's current device is the caller's state: PyTorch's, or another context's).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 }  // namespace
 
 struct snappy_hip_ctx {
@@ -116,6 +132,8 @@ int ws_get(snappy_hip_ctx* c, int slot, size_t bytes, void** out) {
   return SNAPPY_HIP_OK;
 }
 
+extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_t* launches);
+
 struct LaunchTimer {
   snappy_hip_ctx* c;
   hipStream_t s;
@@ -129,6 +147,7 @@ struct LaunchTimer {
     if (a && b) {
       (void)hipEventRecord(b, s);
       c->timed.push_back({a, b, which});
+      if (c->timed.size() >= 4096) (void)snappy_hip_ctx_kernel_ms(c, -1, nullptr);  // fold them into the sums
     }
   }
 };
@@ -195,17 +214,8 @@ void build_probe_sequence(uint32_t* off, uint32_t* step) {
 // =============================================================================================
 extern "C" const char* snappy_hip_last_error(void) { return g_last_error.c_str(); }
 
-extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
-  *out = nullptr;
-  int count = 0;
-  HIP_TRY(hipGetDeviceCount(&count));
-  if (device < 0 || device >= count) {
-    g_last_error = "no such HIP device";
-    return SNAPPY_HIP_DEVICE_ERROR;
-  }
-  HIP_TRY(hipSetDevice(device));
-  snappy_hip_ctx* c = new snappy_hip_ctx();
-  c->device = device;
+namespace {
+int ctx_init(snappy_hip_ctx* c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel,
@@ -226,14 +236,34 @@ extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
   HIP_TRY(hipMemcpy(c->d_col_mul, mul.data(), mul.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_seq_off, so.data(), so.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_seq_step, ss.data(), ss.size() * 4, hipMemcpyHostToDevice));
+  return SNAPPY_HIP_OK;
+}
+}  // namespace
+
+extern "C" int snappy_hip_ctx_create(snappy_hip_ctx** out, int device) {
+  *out = nullptr;
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) {
+    g_last_error = "no such HIP device";
+    return SNAPPY_HIP_DEVICE_ERROR;
+  }
+  DeviceGuard guard(device);  // (the caller's current device is the caller's again on return)
+  snappy_hip_ctx* c = new snappy_hip_ctx();
+  c->device = device;
+  const int st = ctx_init(c);
+  if (st) {
+    snappy_hip_ctx_destroy(c);  // (tolerates a partly built context)
+    return st;
+  }
   *out = c;
   return SNAPPY_HIP_OK;
 }
 
 extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  DeviceGuard guard(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& t : c->timed) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
@@ -244,11 +274,12 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_col_mul);
   (void)hipFree(c->d_seq_off);
   (void)hipFree(c->d_seq_step);
-  (void)hipStreamDestroy(c->stream);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 extern "C" int snappy_hip_ctx_sync(snappy_hip_ctx* c, void* stream) {
+  DeviceGuard guard(c->device);
   HIP_TRY(hipStreamSynchronize(pick_stream(c, stream)));
   return SNAPPY_HIP_OK;
 }
@@ -270,6 +301,7 @@ extern "C" int snappy_hip_ctx_timing(snappy_hip_ctx* c, int enable) {
 }
 
 extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_t* launches) {
+  DeviceGuard guard(c->device);
   for (auto& t : c->timed) {
     float ms = 0;
     if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
@@ -292,6 +324,7 @@ extern "C" int snappy_hip_crc32c_d(snappy_hip_ctx* c, const uint8_t* d_in, const
                                    const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc,
                                    void* stream) {
   if (n_units == 0) return SNAPPY_HIP_OK;
+  DeviceGuard guard(c->device);
   CrcParams p{};
   p.in = d_in;
   p.off = d_off;
@@ -342,6 +375,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   uint64_t nb = (total_len + block_len - 1) / block_len;
   if (nb == 0) return SNAPPY_HIP_OK;
   if (nb > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
   uint32_t* d_crc = nullptr;
   if (unit == kUnitFrame) {
@@ -401,6 +435,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
 extern "C" int snappy_hip_pack_d(snappy_hip_ctx* c, const uint8_t* d_slots, uint32_t slot_stride,
                                  const uint32_t* d_sizes, uint64_t n_blocks, uint64_t base,
                                  uint8_t* d_out, uint64_t* d_offsets, void* stream) {
+  DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
   LaunchTimer lt(c, s, 3);
   hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_sizes, n_blocks, base,
@@ -578,6 +613,7 @@ extern "C" int snappy_hip_decode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
                                           uint32_t* d_out_len, uint32_t* d_status, uint32_t* d_crc,
                                           void* stream) {
   if (unit != kUnitBody && unit != kUnitRaw) return SNAPPY_HIP_INVALID_INPUT;
+  DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
   return decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off, d_out_cap,
                   d_out_len, d_status, true, s, d_crc);
