@@ -124,10 +124,24 @@ int snappy_hip_decode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const u
 /* Masked CRC32C of n_units byte ranges d_in[d_off[i] ..+ d_len[i]] into d_crc[i]. */
 int snappy_hip_crc32c_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_off,
                         const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc, void* stream);
+/* compressFramed, snappy.nim:130-155, for an input RESIDENT IN HBM: stream identifier + one chunk
+ * per 65536-byte slice (encodeFrame, snappy/encoder.nim:385-426) packed into d_out[0 .. *written).
+ * cap >= snappy_hip_max_compressed_len_framed(n), else SNAPPY_HIP_BUFFER_TOO_SMALL.  Returns when
+ * the stream is complete (*written is host memory). */
+int snappy_hip_compress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
+                                 uint64_t cap, uint64_t* written, void* stream);
+/* uncompressFramed, snappy.nim:169-267, for a stream RESIDENT IN HBM: the chunk walk
+ * (snappy.nim:199-265), the block decode, the CRC comparison (:231-233, :244-246) and the choice of
+ * the first failing chunk in stream order all run on the device; the decoded bytes stay in d_out.
+ * Same contract as snappy_hip_uncompress_framed, resume protocol included: status, and on ok the
+ * two counters (*read, *written: host memory).  Returns when the verdict is known. */
+int snappy_hip_uncompress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
+                                   uint64_t cap, int check_header, int check_integrity,
+                                   uint64_t* read, uint64_t* written, void* stream);
 /* Average duration in milliseconds of the last timed kernel launches, measured with HIP
  * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
  * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,
- * 3 pack, 4 decode index pass, 5 whole-stream decode pass.  Timing is recorded only between
+ * 3 pack, 4 decode index pass, 5 whole-stream decode pass, 6 framed chunk walk.  Timing is recorded only between
  * snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */
 int snappy_hip_ctx_timing(snappy_hip_ctx* ctx, int enable);
 double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* ctx, int which, uint64_t* launches);

@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "snappy_hip_ctx_destroy", "snappy_hip_ctx_sync", "snappy_hip_last_error",
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
+    "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d",
 ]
 
 
@@ -87,6 +88,12 @@ lib.snappy_hip_pack_d.argtypes = [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint6
 lib.snappy_hip_decode_blocks_d.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
                                            _vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.snappy_hip_crc32c_d.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint64, _vp, _vp]
+lib.snappy_hip_compress_framed_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
+                                             ctypes.POINTER(ctypes.c_uint64), _vp]
+lib.snappy_hip_uncompress_framed_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
+                                               ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_uint64),
+                                               ctypes.POINTER(ctypes.c_uint64), _vp]
 lib.snappy_hip_ctx_timing.argtypes = [_vp, ctypes.c_int]
 lib.snappy_hip_ctx_kernel_ms.restype = ctypes.c_double
 lib.snappy_hip_ctx_kernel_ms.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
@@ -309,6 +316,27 @@ class Context:
             self._h, _ptr(d_in), _ptr(d_off), _ptr(d_len), n_units, _ptr(d_crc), stream))
         if st != OK:
             raise ValueError("crc32c: status %d" % st)
+
+    def compress_framed(self, d_in, n, d_out, cap, stream=None):
+        """compressFramed of d_in[0:n] (device) into d_out (device); returns the stream's length."""
+        _after_torch(stream, d_in, d_out)
+        w = ctypes.c_uint64()
+        st = _check_device(lib.snappy_hip_compress_framed_d(
+            self._h, _ptr(d_in), n, _ptr(d_out), cap, ctypes.byref(w), stream))
+        if st != OK:
+            raise ValueError("compress_framed: status %d" % st)
+        return w.value
+
+    def uncompress_framed(self, d_in, n, d_out, cap, check_header=True, check_integrity=True,
+                          stream=None):
+        """uncompressFramed of the stream d_in[0:n] (device) into d_out (device): (status, read,
+        written), the reference's Result[(read, written), FrameError]."""
+        _after_torch(stream, d_in, d_out)
+        r, w = ctypes.c_uint64(), ctypes.c_uint64()
+        st = _check_device(lib.snappy_hip_uncompress_framed_d(
+            self._h, _ptr(d_in), n, _ptr(d_out), cap, int(check_header), int(check_integrity),
+            ctypes.byref(r), ctypes.byref(w), stream))
+        return st, r.value, w.value
 
     def timing(self, enable):
         lib.snappy_hip_ctx_timing(self._h, int(enable))

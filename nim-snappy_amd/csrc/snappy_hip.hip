@@ -20,6 +20,7 @@
 #include "decode2_kernel.h"
 #include "decode_kernel.h"
 #include "encode_kernel.h"
+#include "framed_kernels.h"
 #include "index_kernel.h"
 
 using namespace snappy_hip;
@@ -617,6 +618,140 @@ extern "C" int snappy_hip_decode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   hipStream_t s = pick_stream(c, stream);
   return decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off, d_out_cap,
                   d_out_len, d_status, true, s, d_crc);
+}
+
+// compressFramed (snappy.nim:130-155) for an input that is resident in HBM: the stream identifier,
+// then one chunk per 65 536-byte slice (encodeFrame, encoder.nim:385-426, in the encode kernel),
+// packed contiguously.  *written (host) receives the stream's length; the call returns when the
+// stream is complete (it reads the scanned total back).
+extern "C" int snappy_hip_compress_framed_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t n,
+                                            uint8_t* d_out, uint64_t cap, uint64_t* written,
+                                            void* stream) {
+  *written = 0;
+  if (cap < snappy_hip_max_compressed_len_framed((int64_t)n)) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:139-140
+  DeviceGuard guard(c->device);
+  hipStream_t s = pick_stream(c, stream);
+  HIP_TRY(hipMemcpyAsync(d_out, kFramingHeader, sizeof kFramingHeader, hipMemcpyHostToDevice, s));
+  const uint64_t nb = (n + kMaxBlockLen - 1) / kMaxBlockLen;
+  uint64_t end = sizeof kFramingHeader;
+  if (nb) {
+    void *d_slots, *d_sizes, *d_offsets;
+    int st;
+    if ((st = ws_get(c, 17, nb * (size_t)kSlotStride, &d_slots))) return st;
+    if ((st = ws_get(c, 18, nb * 4 + (nb + 1) * 8 + 64, &d_sizes))) return st;
+    d_offsets = (uint8_t*)d_sizes + ((nb * 4 + 15) & ~(size_t)15);
+    if ((st = snappy_hip_encode_blocks_d(c, d_in, n, kMaxBlockLen, kUnitFrame, (uint8_t*)d_slots, kSlotStride,
+                                         (uint32_t*)d_sizes, s)))
+      return st;
+    if ((st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, nb,
+                                sizeof kFramingHeader, d_out, (uint64_t*)d_offsets, s)))
+      return st;
+    HIP_TRY(hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  *written = end;
+  return SNAPPY_HIP_OK;
+}
+
+// uncompressFramed (snappy.nim:169-267) for a stream that is resident in HBM: chunk walk, block
+// decode, CRC comparison and the first-failure verdict all run on the device (framed_kernels.h);
+// what comes back to the host is the verdict: status and the two counters.
+extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t n,
+                                              uint8_t* d_out, uint64_t cap, int check_header,
+                                              int check_integrity, uint64_t* read_out,
+                                              uint64_t* written_out, void* stream) {
+  *read_out = 0;
+  *written_out = 0;
+  DeviceGuard guard(c->device);
+  hipStream_t s = pick_stream(c, stream);
+  FrameScanResult res{};
+  FrameUnits comp{}, stored{};
+  uint32_t *comp_status = nullptr, *comp_len = nullptr, *comp_crc = nullptr, *stored_crc = nullptr;
+  FrameScanResult* d_res = nullptr;
+  FrameVerdict* d_verdict = nullptr;
+  for (int attempt = 0;; attempt++) {
+    // chunk lists: room for one chunk per KiB of stream at first; a stream of tinier chunks (a data
+    // chunk takes at least 8 bytes) gets lists for the worst case on the second attempt
+    const uint64_t want = attempt == 0 ? n / 1024 + 4096 : n / 8 + 16;
+    if (want > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+    const size_t cap_l = (size_t)want;
+    const size_t per_list = cap_l * (8 + 4 + 8 + 4 + 4 + 4 + 8);
+    void* base;
+    int st = ws_get(c, 19, 2 * per_list + cap_l * 16 + 256, &base);
+    if (st) return st;
+    uint8_t* q = (uint8_t*)base;
+    auto carve = [&](FrameUnits* u) {
+      u->in_off = (uint64_t*)q, q += cap_l * 8;
+      u->out_off = (uint64_t*)q, q += cap_l * 8;
+      u->hdr_at = (uint64_t*)q, q += cap_l * 8;
+      u->in_len = (uint32_t*)q, q += cap_l * 4;
+      u->out_cap = (uint32_t*)q, q += cap_l * 4;
+      u->crc = (uint32_t*)q, q += cap_l * 4;
+      u->seq = (uint32_t*)q, q += cap_l * 4;
+    };
+    carve(&comp);
+    carve(&stored);
+    comp_status = (uint32_t*)q, q += cap_l * 4;
+    comp_len = (uint32_t*)q, q += cap_l * 4;
+    comp_crc = (uint32_t*)q, q += cap_l * 4;
+    stored_crc = (uint32_t*)q, q += cap_l * 4;
+    d_res = (FrameScanResult*)q, q += 128;
+    d_verdict = (FrameVerdict*)q;
+    FrameScanParams sp{};
+    sp.in = d_in;
+    sp.n = n;
+    sp.cap = cap;
+    sp.check_header = check_header;
+    sp.check_integrity = check_integrity;
+    sp.comp = comp;
+    sp.stored = stored;
+    sp.list_cap = (uint32_t)cap_l;
+    sp.res = d_res;
+    {
+      LaunchTimer lt(c, s, 6);
+      hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(64), 0, s, sp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!res.overflow) break;
+    if (attempt == 1) {
+      g_last_error = "internal: chunk lists overflowed twice";
+      return SNAPPY_HIP_DEVICE_ERROR;
+    }
+  }
+  if (res.n_comp) {  // compressed chunks: uncompress() each (snappy.nim:216), checksummed from the decoder's window
+    int st = decode_d(c, d_in, comp.in_off, comp.in_len, res.n_comp, kUnitRaw, nullptr, d_out, comp.out_off,
+                      comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr);
+    if (st) return st;
+  }
+  if (res.n_stored) {  // stored chunks: checksum the payload (snappy.nim:244), then copy it (:256)
+    if (check_integrity) {
+      int st = snappy_hip_crc32c_d(c, d_in, stored.in_off, stored.in_len, res.n_stored, stored_crc, s);
+      if (st) return st;
+    }
+    hipLaunchKernelGGL(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
+                       stored.out_off, d_res, d_out);
+    HIP_TRY(hipGetLastError());
+  }
+  FrameVerdictParams vp{};
+  vp.comp = comp;
+  vp.stored = stored;
+  vp.res = d_res;
+  vp.comp_status = comp_status;
+  vp.comp_crc = comp_crc;
+  vp.stored_crc = stored_crc;
+  vp.check_integrity = check_integrity;
+  vp.out = d_verdict;
+  hipLaunchKernelGGL(frame_verdict_kernel, dim3(1), dim3(1024), 0, s, vp);
+  HIP_TRY(hipGetLastError());
+  FrameVerdict v{};
+  HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (v.status != kOk) return (int)v.status;
+  *read_out = v.read;
+  *written_out = v.written;
+  return SNAPPY_HIP_OK;
 }
 
 // =============================================================================================
