@@ -11,7 +11,10 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -810,52 +813,203 @@ extern "C" int snappy_hip_uncompressed_len_framed(const uint8_t* in, size_t n, u
 // =============================================================================================
 namespace {
 
-std::mutex g_mu;
-snappy_hip_ctx* g_ctx = nullptr;
+// The host-buffer calls run on contexts from a pool: a call takes a free context (or makes one),
+// and gives it back when it returns, so concurrent callers -- the reference's API is re-entrant --
+// run side by side, each on its own stream and scratch buffers, and the number of contexts is the
+// largest number of calls that ever ran at once.  (SNAPPY_HIP_DEVICE picks the GPU.)
+std::mutex g_pool_mu;
+std::vector<snappy_hip_ctx*> g_pool;
 
-int default_ctx(snappy_hip_ctx** out) {
-  if (!g_ctx) {
-    int dev = 0;
-    if (const char* e = getenv("SNAPPY_HIP_DEVICE")) dev = atoi(e);
-    int st = snappy_hip_ctx_create(&g_ctx, dev);
-    if (st) return st;
+struct CtxLease {
+  snappy_hip_ctx* c = nullptr;
+  int status = SNAPPY_HIP_OK;
+  CtxLease() {
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if (!g_pool.empty()) {
+        c = g_pool.back();
+        g_pool.pop_back();
+      }
+    }
+    if (!c) {
+      int dev = 0;
+      if (const char* e = getenv("SNAPPY_HIP_DEVICE")) dev = atoi(e);
+      status = snappy_hip_ctx_create(&c, dev);
+      if (status) c = nullptr;
+    }
+    if (c) guard = new DeviceGuard(c->device);
   }
-  HIP_TRY(hipSetDevice(g_ctx->device));
-  *out = g_ctx;
-  return SNAPPY_HIP_OK;
+  ~CtxLease() {
+    delete guard;
+    if (c) {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      g_pool.push_back(c);
+    }
+  }
+  CtxLease(const CtxLease&) = delete;
+  CtxLease& operator=(const CtxLease&) = delete;
+
+ private:
+  DeviceGuard* guard = nullptr;
+};
+
+// A caller's buffer, page-locked in place for the duration of a call: copies from and to it are
+// then real DMA transfers that overlap with each other and with kernels (measured on the GPU box:
+// 56 GB/s each way at once, against 28 GB/s each way from pageable memory; registering 512 MiB takes
+// 5 ms).  If the range cannot be registered (it already is, for instance) copies fall back to the
+// runtime's pageable path.
+constexpr size_t kPinMin = 1u << 20;
+// SNAPPY_HIP_PIN_HOST (read once): 0 = never, pageable copies (default: measured fastest, see
+// INTEGRATION.md), 1 = page-lock the caller's whole buffers for the call, 2 = batch by batch.
+inline int pin_mode() {
+  static const int mode = [] {
+    const char* e = getenv("SNAPPY_HIP_PIN_HOST");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
+struct HostPin {
+  void* p = nullptr;
+  HostPin(const void* ptr, size_t n, int when = 1) {
+    if (pin_mode() == when && n >= kPinMin && hipHostRegister(const_cast<void*>(ptr), n, hipHostRegisterDefault) == hipSuccess)
+      p = const_cast<void*>(ptr);
+    else
+      (void)hipGetLastError();
+  }
+  ~HostPin() {
+    if (p) (void)hipHostUnregister(p);
+  }
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+};
+
+// Runs fn(batch index, context) for every batch: one batch inline, several on up to three worker
+// threads, each with a context of its own -- the upload of one batch, the kernels of another and the
+// download of a third then overlap.  Returns the first non-zero status.
+template <typename F>
+int run_batches(size_t n_batches, snappy_hip_ctx* own, F fn) {
+  if (n_batches <= 1) return n_batches ? fn((size_t)0, own) : SNAPPY_HIP_OK;
+  const size_t n_workers = n_batches < 3 ? n_batches : 3;
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_err{SNAPPY_HIP_OK};
+  std::vector<std::string> errs(n_workers);
+  auto work = [&](size_t w, snappy_hip_ctx* c) {
+    for (;;) {
+      const size_t b = next.fetch_add(1);
+      if (b >= n_batches) break;
+      const int st = fn(b, c);
+      if (st) {
+        int exp = SNAPPY_HIP_OK;
+        if (first_err.compare_exchange_strong(exp, st)) errs[w] = g_last_error;
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t w = 1; w < n_workers; w++)
+    threads.emplace_back([&, w] {
+      CtxLease lease;
+      if (!lease.c) {
+        int exp = SNAPPY_HIP_OK;
+        if (first_err.compare_exchange_strong(exp, lease.status)) errs[w] = g_last_error;
+        return;
+      }
+      work(w, lease.c);
+    });
+  work(0, own);
+  for (auto& t : threads) t.join();
+  const int st = first_err.load();
+  if (st)
+    for (auto& e : errs)
+      if (!e.empty()) g_last_error = e;
+  return st;
 }
 
-// Encode `n` host bytes as units of `block_len` and land the packed stream (from byte `base`)
-// in out[base ..]; *total = end offset.
-int encode_host(const uint8_t* in, size_t n, int unit, uint8_t* out, size_t cap, uint64_t base,
-                uint64_t* total) {
-  snappy_hip_ctx* c;
-  int st = default_ctx(&c);
-  if (st) return st;
+// Encode `n` host bytes as units of 65 536 bytes and land the packed stream (from byte `base`) in
+// out[base ..]; *total = end offset.  The input goes in batches of 64 MiB: a batch is uploaded,
+// encoded and packed on one context while its neighbours are on theirs (run_batches); a batch's
+// place in the output is the sum of the batches in front of it -- the reference's serial
+// `written += ...` (snappy.nim:59-62, :149-153) -- so its download waits for their sizes only.
+inline uint64_t host_batch_blocks() {  // SNAPPY_HIP_HOST_BATCH (read once): blocks per batch
+  static const uint64_t v = [] {
+    const char* e = getenv("SNAPPY_HIP_HOST_BATCH");
+    const long x = e ? atol(e) : 0;
+    return (uint64_t)(x >= 64 && x <= 65536 ? x : 2048);  // (measured: INTEGRATION.md)
+  }();
+  return v;
+}
+
+int encode_host(snappy_hip_ctx* own, const uint8_t* in, size_t n, int unit, uint8_t* out, size_t cap,
+                uint64_t base, uint64_t* total) {
   const uint64_t nb = (n + kMaxBlockLen - 1) / kMaxBlockLen;
-  void *d_in, *d_slots, *d_sizes, *d_offsets, *d_out;
-  if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
-  if ((st = ws_get(c, 1, nb * (size_t)kSlotStride, &d_slots))) return st;
-  if ((st = ws_get(c, 2, nb * 4, &d_sizes))) return st;
-  if ((st = ws_get(c, 3, (nb + 1) * 8, &d_offsets))) return st;
-  if ((st = ws_get(c, 4, cap + 64, &d_out))) return st;
-  hipStream_t s = c->stream;
-  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
-  if ((st = snappy_hip_encode_blocks_d(c, (const uint8_t*)d_in, n, kMaxBlockLen, unit,
-                                       (uint8_t*)d_slots, kSlotStride, (uint32_t*)d_sizes, s)))
-    return st;
-  if ((st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes,
-                              nb, base, (uint8_t*)d_out, (uint64_t*)d_offsets, s)))
-    return st;
-  uint64_t end = 0;
-  HIP_TRY(hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (end > cap) {
-    g_last_error = "internal: packed stream exceeds the caller's bound";
-    return SNAPPY_HIP_DEVICE_ERROR;
-  }
-  HIP_TRY(hipMemcpyAsync(out + base, (uint8_t*)d_out + base, end - base, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  const uint64_t kHostBatchBlocks = host_batch_blocks();
+  const size_t n_batches = (size_t)((nb + kHostBatchBlocks - 1) / kHostBatchBlocks);
+  const uint64_t bound = base + nb * (uint64_t)(kMaxCompressedBlockLen + 16);  // what can be produced at most
+  HostPin pin_in(in, n), pin_out(out, (size_t)(bound < cap ? bound : cap));
+  std::vector<uint64_t> sizes(n_batches, 0);
+  std::vector<char> ready(n_batches, 0);
+  std::mutex mu;
+  std::condition_variable cv;
+  bool failed = false;
+  auto fn = [&](size_t b, snappy_hip_ctx* c) -> int {
+    auto fail = [&](int st) {
+      std::lock_guard<std::mutex> lk(mu);
+      failed = true;
+      cv.notify_all();
+      return st;
+    };
+    const uint64_t b0 = b * kHostBatchBlocks;
+    const uint64_t cnt = nb - b0 < kHostBatchBlocks ? nb - b0 : kHostBatchBlocks;
+    const size_t in_lo = (size_t)(b0 * kMaxBlockLen);
+    const size_t in_n = n - in_lo < cnt * kMaxBlockLen ? n - in_lo : (size_t)(cnt * kMaxBlockLen);
+    void *d_in, *d_slots, *d_sizes, *d_offsets, *d_out;
+    int st;
+    if ((st = ws_get(c, 0, in_n + 64, &d_in))) return fail(st);
+    if ((st = ws_get(c, 1, cnt * (size_t)kSlotStride, &d_slots))) return fail(st);
+    if ((st = ws_get(c, 2, cnt * 4, &d_sizes))) return fail(st);
+    if ((st = ws_get(c, 3, (cnt + 1) * 8, &d_offsets))) return fail(st);
+    if ((st = ws_get(c, 4, cnt * (size_t)kSlotStride + 64, &d_out))) return fail(st);
+    hipStream_t s = c->stream;
+    HostPin pin_in(in + in_lo, in_n, 2);
+    if (hipMemcpyAsync(d_in, in + in_lo, in_n, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SNAPPY_HIP_DEVICE_ERROR);
+    if ((st = snappy_hip_encode_blocks_d(c, (const uint8_t*)d_in, in_n, kMaxBlockLen, unit, (uint8_t*)d_slots,
+                                         kSlotStride, (uint32_t*)d_sizes, s)))
+      return fail(st);
+    if ((st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, cnt, 0,
+                                (uint8_t*)d_out, (uint64_t*)d_offsets, s)))
+      return fail(st);
+    uint64_t end = 0;
+    if (hipMemcpyAsync(&end, (uint64_t*)d_offsets + cnt, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return fail(SNAPPY_HIP_DEVICE_ERROR);
+    uint64_t at = base;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      sizes[b] = end;
+      ready[b] = 1;
+      cv.notify_all();
+      cv.wait(lk, [&] {
+        if (failed) return true;
+        for (size_t j = 0; j < b; j++)
+          if (!ready[j]) return false;
+        return true;
+      });
+      if (failed) return SNAPPY_HIP_DEVICE_ERROR;
+      for (size_t j = 0; j < b; j++) at += sizes[j];
+    }
+    if (at + end > cap) {
+      g_last_error = "internal: packed stream exceeds the caller's bound";
+      return fail(SNAPPY_HIP_DEVICE_ERROR);
+    }
+    HostPin pin_out(out + at, (size_t)end, 2);
+    if (hipMemcpyAsync(out + at, d_out, end, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return fail(SNAPPY_HIP_DEVICE_ERROR);
+    return SNAPPY_HIP_OK;
+  };
+  const int st = run_batches(n_batches, own, fn);
+  if (st) return st;
+  uint64_t end = base;
+  for (size_t j = 0; j < n_batches; j++) end += sizes[j];
   *total = end;
   return SNAPPY_HIP_OK;
 }
@@ -868,15 +1022,13 @@ struct HostUnit {
   uint8_t kind;
 };
 
-// Run units on the device: input bytes in[0..n) are uploaded once, outputs land in
-// out[0..out_bytes); per-unit status / length / crc come back in the vectors.
-int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units, uint8_t* out,
-                size_t out_bytes, bool want_crc, std::vector<uint32_t>* status,
-                std::vector<uint32_t>* out_len, std::vector<uint32_t>* crc,
-                bool copy_out = true) {
-  snappy_hip_ctx* c;
-  int st = default_ctx(&c);
-  if (st) return st;
+// Run units on the device: input bytes in[0..n) are uploaded once, outputs land in the context's
+// output buffer (out_bytes of it), the first copy_bytes of which are copied to out; per-unit
+// status / length / crc come back in the vectors.
+int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
+                uint8_t* out, size_t out_bytes, bool want_crc, std::vector<uint32_t>* status,
+                std::vector<uint32_t>* out_len, std::vector<uint32_t>* crc, size_t copy_bytes) {
+  int st;
   const size_t nu = units.size();
   status->assign(nu, 0);
   out_len->assign(nu, 0);
@@ -944,8 +1096,7 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
   if (want_crc) HIP_TRY(hipMemcpyAsync(crc->data(), d_crc, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(status->data(), d_st, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_len->data(), d_ol, nu * 4, hipMemcpyDeviceToHost, s));
-  if (out_bytes && copy_out)
-    HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+  if (copy_bytes) HIP_TRY(hipMemcpyAsync(out, d_out, copy_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   {  // back to the caller's unit order
     std::vector<uint32_t> t(nu);
@@ -962,12 +1113,10 @@ int decode_host(const uint8_t* in, size_t n, const std::vector<HostUnit>& units,
 // output starts (index_units_kernel<true>); the blocks are then decoded in parallel like
 // independent units.  Returns -1 when that does not apply (an element or a copy crosses a 64 KiB
 // output boundary, possible with foreign encoders): the caller then uses the serial kernel.
-int uncompress_split_host(const uint8_t* in, size_t n, uint32_t hdr, uint64_t len, uint8_t* out,
-                          size_t* written) {
+int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32_t hdr, uint64_t len,
+                          uint8_t* out, size_t* written) {
   if (len > (1ull << 31) || n > (1ull << 31)) return -1;
-  snappy_hip_ctx* c;
-  int st = default_ctx(&c);
-  if (st) return st;
+  int st;
   const size_t nblk = (size_t)((len + kMaxBlockLen - 1) / kMaxBlockLen);
   void *d_in, *d_out, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_blk, *d_one;
   if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
@@ -1060,15 +1209,12 @@ extern "C" int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, si
   if ((uint64_t)n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:41-42
   if ((uint64_t)cap < snappy_hip_max_compressed_len((uint32_t)n))    // snappy.nim:44-45
     return SNAPPY_HIP_BUFFER_TOO_SMALL;
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLease lease;  // (an empty input still refuses to run without a device)
+  if (!lease.c) return lease.status;
   const int hl = varint_encode_u32((uint32_t)n, out);  // snappy.nim:49-50
   uint64_t total = (uint64_t)hl;
   if (n) {
-    int st = encode_host(in, n, kUnitBody, out, cap, (uint64_t)hl, &total);
-    if (st) return st;
-  } else {
-    snappy_hip_ctx* c;  // still refuse to run without a device
-    int st = default_ctx(&c);
+    int st = encode_host(lease.c, in, n, kUnitBody, out, cap, (uint64_t)hl, &total);
     if (st) return st;
   }
   *written = (size_t)total;
@@ -1081,9 +1227,10 @@ extern "C" int snappy_hip_encode_block(const uint8_t* in, size_t n, uint8_t* out
   if (n == 0 || n > kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // encoder.nim:208-209
   if ((uint64_t)cap + 16 <= snappy_hip_max_compressed_len((uint32_t)n))  // encoder.nim:217
     return SNAPPY_HIP_BUFFER_TOO_SMALL;
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLease lease;
+  if (!lease.c) return lease.status;
   uint64_t total = 0;
-  int st = encode_host(in, n, kUnitBody, out, cap, 0, &total);
+  int st = encode_host(lease.c, in, n, kUnitBody, out, cap, 0, &total);
   if (st) return st;
   *written = (size_t)total;
   return SNAPPY_HIP_OK;
@@ -1095,9 +1242,10 @@ extern "C" int snappy_hip_encode_frame(const uint8_t* in, size_t n, uint8_t* out
   if (n == 0 || n > kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // encoder.nim:388
   if ((uint64_t)cap < snappy_hip_max_compressed_len((uint32_t)n))   // encoder.nim:392
     return SNAPPY_HIP_BUFFER_TOO_SMALL;
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLease lease;
+  if (!lease.c) return lease.status;
   uint64_t total = 0;
-  int st = encode_host(in, n, kUnitFrame, out, cap, 0, &total);
+  int st = encode_host(lease.c, in, n, kUnitFrame, out, cap, 0, &total);
   if (st) return st;
   *written = (size_t)total;
   return SNAPPY_HIP_OK;
@@ -1108,15 +1256,12 @@ extern "C" int snappy_hip_compress_framed(const uint8_t* in, size_t n, uint8_t* 
   *written = 0;
   if ((uint64_t)cap < snappy_hip_max_compressed_len_framed((int64_t)n))  // snappy.nim:139-140
     return SNAPPY_HIP_BUFFER_TOO_SMALL;
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLease lease;
+  if (!lease.c) return lease.status;
   memcpy(out, kFramingHeader, sizeof kFramingHeader);  // snappy.nim:142
   uint64_t total = sizeof kFramingHeader;
   if (n) {
-    int st = encode_host(in, n, kUnitFrame, out, cap, sizeof kFramingHeader, &total);
-    if (st) return st;
-  } else {
-    snappy_hip_ctx* c;
-    int st = default_ctx(&c);
+    int st = encode_host(lease.c, in, n, kUnitFrame, out, cap, sizeof kFramingHeader, &total);
     if (st) return st;
   }
   *written = (size_t)total;
@@ -1124,15 +1269,16 @@ extern "C" int snappy_hip_compress_framed(const uint8_t* in, size_t n, uint8_t* 
 }
 
 extern "C" uint32_t snappy_hip_masked_crc32c(const uint8_t* buf, size_t n, int* status) {
-  std::lock_guard<std::mutex> lk(g_mu);
   auto fail = [&](int st) -> uint32_t {
     if (status) *status = st;
     return 0;
   };
   if (n > 0xffffffffull) return fail(SNAPPY_HIP_INVALID_INPUT);  // crc32c.c:761 truncates; we refuse
-  snappy_hip_ctx* c;
-  int st = default_ctx(&c);
-  if (st) return fail(st);
+  CtxLease lease;
+  if (!lease.c) return fail(lease.status);
+  snappy_hip_ctx* c = lease.c;
+  int st;
+  HostPin pin(buf, n);
   void *d_in, *d_off, *d_len, *d_crc;
   if ((st = ws_get(c, 0, n + 64, &d_in))) return fail(st);
   if ((st = ws_get(c, 3, 8, &d_off))) return fail(st);
@@ -1163,15 +1309,17 @@ extern "C" int snappy_hip_uncompress(const uint8_t* in, size_t n, uint8_t* out, 
   if (hdr <= 0) return SNAPPY_HIP_INVALID_INPUT;
   if ((uint64_t)cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
   if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;       // unit lengths are 32-bit
-  std::lock_guard<std::mutex> lk(g_mu);
+  CtxLease lease;
+  if (!lease.c) return lease.status;
+  HostPin pin_in(in, n), pin_out(out, (size_t)len);
   if (len > kMaxBlockLen && !dbg_env("SNAPPY_HIP_NO_SPLIT")) {  // several blocks: split, then decode in parallel
-    const int rs = uncompress_split_host(in, n, (uint32_t)hdr, len, out, written);
+    const int rs = uncompress_split_host(lease.c, in, n, (uint32_t)hdr, len, out, written);
     if (rs >= 0) return rs;
   }
   // the kernel re-parses the header: one RAW unit, output window = the declared length
   std::vector<HostUnit> units{{0, (uint32_t)n, 0, (uint32_t)len, (uint8_t)kUnitRaw}};
   std::vector<uint32_t> st, ol, crc;
-  int rc = decode_host(in, n, units, out, (size_t)len, false, &st, &ol, &crc);
+  int rc = decode_host(lease.c, in, n, units, out, (size_t)len, false, &st, &ol, &crc, (size_t)len);
   if (rc) return rc;
   if (st[0] != kOk) return (int)st[0];
   *written = ol[0];
@@ -1185,10 +1333,10 @@ extern "C" int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* 
   if (cap == 0) return SNAPPY_HIP_BUFFER_TOO_SMALL;    // decoder.nim:29-30
   if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;
   const uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
-  std::lock_guard<std::mutex> lk(g_mu);
-  snappy_hip_ctx* c;
-  int rc = default_ctx(&c);
-  if (rc) return rc;
+  CtxLease lease;
+  if (!lease.c) return lease.status;
+  snappy_hip_ctx* c = lease.c;
+  int rc;
   // The output length is not known up front.  A stream of n bytes cannot expand to more than
   // 64 bytes per 3 (copy2), so the device buffer is bounded by that; the unit's limit stays
   // the caller's capacity.  Only the bytes actually produced are copied back.
@@ -1196,7 +1344,7 @@ extern "C" int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* 
   const size_t dev_out = (size_t)(bound < cap32 ? bound : cap32);
   std::vector<HostUnit> units{{0, (uint32_t)n, 0, cap32, (uint8_t)kUnitBody}};
   std::vector<uint32_t> st, ol, crc;
-  rc = decode_host(in, n, units, out, dev_out, false, &st, &ol, &crc, false);
+  rc = decode_host(c, in, n, units, out, dev_out, false, &st, &ol, &crc, 0);
   if (rc) return rc;
   if (st[0] != kOk) return (int)st[0];
   if (ol[0]) HIP_TRY(hipMemcpy(out, c->ws[4].p, ol[0], hipMemcpyDeviceToHost));
@@ -1229,7 +1377,6 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
   int terminal = -1;          // status that ends the walk (-1: ran to the end of input)
   bool stop_ok = false;       // walk ended because the output is full: ok((read-4, written))
   size_t stop_rd = 0, stop_wr = 0;
-  size_t crc_scratch = 0;  // output-space bytes for crc-only stored chunks (not delivered)
   while (rd < n) {         // snappy.nim:199
     size_t remaining = n - rd;
     if (remaining < 4) {
@@ -1289,7 +1436,6 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
         if (check_integrity) {  // checksum it on the device without delivering it
           units.push_back({rd + 4, (uint32_t)ul, 0, (uint32_t)ul, (uint8_t)kUnitStored});
           chunks.push_back({hdr_at, rd + data_len, crc, true, after});
-          crc_scratch = ul;
         } else if (after == -2) {
           stop_ok = true;
           stop_rd = hdr_at;
@@ -1312,24 +1458,63 @@ extern "C" int snappy_hip_uncompress_framed(const uint8_t* in, size_t n, uint8_t
   const size_t walk_rd = rd;
 
   // ---- device pass ---------------------------------------------------------------------------
-  std::lock_guard<std::mutex> lk(g_mu);
-  // crc-only units write into scratch space placed after the deliverable output
+  // In batches of about 64 MiB of output: a batch's slice of the stream is uploaded, its chunks are
+  // decoded and checksummed, and its bytes are downloaded straight into the caller's buffer, on one
+  // context, while the neighbouring batches are on theirs (run_batches) -- upload, kernels and
+  // download overlap.  Chunks behind a failing one may thus have been delivered as well ("on error
+  // output may have been partially written", snappy.nim:185); the verdict below is the reference's.
   const size_t deliver = wr;
-  for (size_t i = 0; i < units.size(); i++)
-    if (chunks[i].crc_only) units[i].out_off = deliver;
-  std::vector<uint32_t> st, ol, crc;
-  snappy_hip_ctx* c;
-  int rc = default_ctx(&c);
-  if (rc) return rc;
-  // the decoded bytes stay on the device until the verdict is known: only the chunks in front of
-  // the first failing one are delivered, straight into the caller's buffer
-  rc = decode_host(in, n, units, nullptr, deliver + crc_scratch, check_integrity != 0, &st, &ol, &crc,
-                   false);
-  if (rc) return rc;
-  auto deliver_prefix = [&](size_t bytes) -> int {
-    if (bytes) HIP_TRY(hipMemcpy(out, c->ws[4].p, bytes, hipMemcpyDeviceToHost));
+  const size_t nu_all = units.size();
+  for (size_t i = 0; i < nu_all; i++)
+    if (chunks[i].crc_only) units[i].out_off = deliver;  // checksummed in scratch behind the batch's output
+  CtxLease lease;
+  if (!lease.c) return lease.status;
+  HostPin pin_in(in, n), pin_out(out, deliver);
+  std::vector<size_t> batch_lo;  // first unit of each batch
+  {
+    size_t acc_out = 0, acc_in = 0;
+    for (size_t i = 0; i < nu_all; i++) {
+      if (i == 0 || acc_out >= (64u << 20) || acc_in >= (64u << 20)) {
+        batch_lo.push_back(i);
+        acc_out = acc_in = 0;
+      }
+      acc_out += units[i].out_cap;
+      acc_in += units[i].in_len;
+    }
+  }
+  std::vector<uint32_t> st(nu_all), ol(nu_all), crc(nu_all);
+  auto fn = [&](size_t b, snappy_hip_ctx* c) -> int {
+    const size_t lo = batch_lo[b], hi = b + 1 < batch_lo.size() ? batch_lo[b + 1] : nu_all;
+    const uint64_t in_lo = units[lo].in_off, in_hi = units[hi - 1].in_off + units[hi - 1].in_len;
+    const uint64_t out_lo = units[lo].out_off;
+    std::vector<HostUnit> part(units.begin() + lo, units.begin() + hi);
+    uint64_t out_hi = out_lo;  // deliverable bytes end
+    size_t scratch = 0;
+    for (size_t k = 0; k < part.size(); k++) {
+      part[k].in_off -= in_lo;
+      if (chunks[lo + k].crc_only) {
+        scratch = part[k].out_cap;
+      } else {
+        out_hi = part[k].out_off + part[k].out_cap;
+      }
+      part[k].out_off -= out_lo;
+    }
+    std::vector<uint32_t> s1, o1, c1;
+    HostPin pin_in(in + in_lo, (size_t)(in_hi - in_lo), 2), pin_out(out + out_lo, (size_t)(out_hi - out_lo), 2);
+    const int rc = decode_host(c, in + in_lo, (size_t)(in_hi - in_lo), part, out + out_lo,
+                               (size_t)(out_hi - out_lo) + scratch, check_integrity != 0, &s1, &o1, &c1,
+                               (size_t)(out_hi - out_lo));
+    if (rc) return rc;
+    for (size_t k = 0; k < part.size(); k++) {
+      st[lo + k] = s1[k];
+      ol[lo + k] = o1[k];
+      crc[lo + k] = c1[k];
+    }
     return SNAPPY_HIP_OK;
   };
+  int rc = run_batches(batch_lo.size(), lease.c, fn);
+  if (rc) return rc;
+  auto deliver_prefix = [&](size_t) -> int { return SNAPPY_HIP_OK; };  // (delivered by the batches)
 
   // ---- first failure in stream order wins ------------------------------------------------------
   size_t ok_wr = 0;

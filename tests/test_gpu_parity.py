@@ -325,3 +325,30 @@ def test_long_foreign_block_streams_take_the_one_pass_kernel(hip, orc):
     raw = _varint(len(plain)) + body
     assert hip.decode(raw) == plain
     assert hip.uncompress(raw[:-1], len(plain))[0] == orc.uncompress(raw[:-1], len(plain))[0] != bh.OK
+
+
+def test_host_calls_from_several_threads(hip, orc):
+    """the reference's API is re-entrant (all `func`, no globals): concurrent host-buffer calls run on
+    contexts of their own (a pool) and give the oracle's bytes; large inputs go in several batches on
+    worker threads (more than 2048 blocks) and must come out in stream order"""
+    import threading
+    srcs = [golden_file("alice29.txt") * 3, golden_file("html") * 5, cases.mod10(300000),
+            golden_file("urls.10K"), golden_file("kppkn.gtb") * 2, bytes(range(256)) * 2000]
+    got = [None] * len(srcs)
+
+    def work(i):
+        for _ in range(3):
+            enc = hip.encode(srcs[i])
+            fr = hip.encode_framed(srcs[i])
+            assert hip.decode(enc) == srcs[i] and hip.decode_framed(fr) == srcs[i]
+            got[i] = (enc, fr)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(srcs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i, s in enumerate(srcs):
+        assert got[i] == (orc.encode(s), orc.encode_framed(s)), i
+    big = (golden_file("alice29.txt") + golden_file("html") + golden_file("fireworks.jpeg")) * 400  # ~150 MiB, 3 batches
+    assert hip.encode_framed(big) == orc.encode_framed(big)
+    assert hip.decode_framed(hip.encode_framed(big)) == big
+    assert hip.encode(big) == orc.encode(big)
