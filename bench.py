@@ -100,6 +100,15 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         return orc.lib.sor_uncompress_blocks(out.ctypes.data, offs[lo:].ctypes.data, csz[lo:].ctypes.data,
                                              hi - lo, dec.ctypes.data + lo * BLOCK, BLOCK)
 
+    def cpart(k):  # compress, block ranges spread over the same threads
+        lo, hi = k * per, min(n_sample, (k + 1) * per)
+        if lo < hi:
+            orc.lib.sor_compress_blocks(src.ctypes.data + lo * BLOCK, (hi - lo) * BLOCK, BLOCK,
+                                        out2.ctypes.data + lo * slot, slot, csz2.ctypes.data + 4 * lo)
+        return 0
+
+    out2 = np.empty(n_sample * slot, dtype=np.uint8)
+    csz2 = np.empty(n_sample, dtype=np.uint32)
     with cf.ThreadPoolExecutor(nthr) as ex:
         list(ex.map(part, range(nthr)))  # warm
         t0 = time.perf_counter()
@@ -107,6 +116,10 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         for _ in range(mt_passes):
             assert all(r == 0 for r in ex.map(part, range(nthr)))
         t_mt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        list(ex.map(cpart, range(nthr)))
+        t_mt_enc = time.perf_counter() - t0
+    assert np.array_equal(csz2, csz)
     return {
         "value": round(n_sample * BLOCK * passes / t_dec / 1e9, 4),
         "unit": "GB/s uncompressed (decompress)",
@@ -117,8 +130,164 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         "compress_value": round(n_sample * BLOCK / t_enc / 1e9, 4),
         "threads": nthr,
         "threads_value": round(n_sample * BLOCK * mt_passes / t_mt / 1e9, 3),
+        "compress_threads_value": round(n_sample * BLOCK / t_mt_enc / 1e9, 3),
         "host_cpus": os.cpu_count(),
     }
+
+
+def config1_alice29(hip):
+    """BASELINE configs[0]: tests/data/alice29.txt single-buffer encode / decode, timed the way the
+    reference's harness does (tests/benchmark.nim:20-23,93-104: mean over 100 calls, ms per call) --
+    the oracle on one host core (the Nim inMemory path cannot be built here), and the HIP library's
+    host-buffer calls (PCIe and launch latency included: 3 blocks cannot fill a GPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    with open(os.path.join(ROOT, "tests", "golden", "data", "alice29.txt"), "rb") as fh:
+        src = fh.read()
+
+    def mean_ms(f, reps=100):
+        f()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    enc = orc.encode(src)
+    fr = orc.encode_framed(src)
+    assert hip.encode(src) == enc and hip.encode_framed(src) == fr and hip.decode(enc) == src
+    return {
+        "file": "alice29.txt", "bytes": len(src), "calls": 100, "unit": "ms per call (encode / decode)",
+        "oracle_inMemory_raw": [round(mean_ms(lambda: orc.encode(src)), 4), round(mean_ms(lambda: orc.decode(enc)), 4)],
+        "oracle_inMemory_framed": [round(mean_ms(lambda: orc.encode_framed(src)), 4),
+                                   round(mean_ms(lambda: orc.decode_framed(fr)), 4)],
+        "hip_host_api_raw": [round(mean_ms(lambda: hip.encode(src)), 4), round(mean_ms(lambda: hip.decode(enc)), 4)],
+        "hip_host_api_framed": [round(mean_ms(lambda: hip.encode_framed(src)), 4),
+                                round(mean_ms(lambda: hip.decode_framed(fr)), 4)],
+        "reference_README_x86_64": {"raw": [0.334, 0.186], "framed": [0.382, 0.251]},
+    }
+
+
+def host_api_rates(hip, src_np):
+    """The host-buffer C ABI end to end (PCIe copies included; never `value`): GB/s of uncompressed
+    bytes for one call over src_np, and two host threads at once."""
+    import ctypes
+    import threading
+    lib = hip.lib
+    n = src_np.size
+    P = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    C = lambda a: ctypes.cast(P(a), ctypes.c_char_p)  # noqa: E731
+
+    def best(f, reps=2):
+        f()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    cap = hip.max_compressed_len_framed(n)
+    fr = np.empty(cap, dtype=np.uint8)
+    back = np.empty(n, dtype=np.uint8)
+    w, r = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def cf(inp=src_np, out=fr, ww=w):
+        assert lib.snappy_hip_compress_framed(C(inp), inp.size, P(out), out.size, ctypes.byref(ww)) == 0
+
+    def uf():
+        assert lib.snappy_hip_uncompress_framed(C(fr), flen, P(back), n, 1, 1, ctypes.byref(r), ctypes.byref(w)) == 0
+
+    res = {"bytes": int(n)}
+    res["compress_framed_GBps"] = round(n / best(cf) / 1e9, 2)
+    flen = w.value
+    res["uncompress_framed_GBps"] = round(n / best(uf) / 1e9, 2)
+    assert w.value == n and np.array_equal(back, src_np)
+    raw = np.empty(hip.max_compressed_len(n), dtype=np.uint8)
+
+    def cr():
+        assert lib.snappy_hip_compress(C(src_np), n, P(raw), raw.size, ctypes.byref(w)) == 0
+
+    res["compress_GBps"] = round(n / best(cr) / 1e9, 2)
+    rlen = w.value
+    back[:] = 0
+
+    def ur():
+        assert lib.snappy_hip_uncompress(C(raw), rlen, P(back), n, ctypes.byref(w)) == 0
+
+    res["uncompress_GBps"] = round(n / best(ur, reps=1) / 1e9, 2)
+    assert w.value == n and np.array_equal(back, src_np)
+    half = n // 2
+    outs = [np.empty(cap, dtype=np.uint8) for _ in range(2)]
+    ws = [ctypes.c_size_t(), ctypes.c_size_t()]
+
+    def work(i):
+        cf(src_np[i * half:(i + 1) * half], outs[i], ws[i])
+
+    def both():
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+
+    res["compress_framed_half_one_thread_ms"] = round(best(lambda: work(0)) * 1e3, 2)
+    res["compress_framed_halves_two_threads_ms"] = round(best(both) * 1e3, 2)
+    return res
+
+
+def per_class_rates(hip, corpus, ctx, dev, nb):
+    """Every corpus class alone ("also report each class alone"), nb blocks each:
+    device-resident compress and block decompress, kernel times from HIP events."""
+    out = {}
+    for cls in corpus.CLASSES:
+        d_in = corpus.make_blocks_torch(torch, 0, nb, dev, only=cls).reshape(-1)
+        d_slots = torch.empty(nb * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
+        d_sizes = torch.empty(nb, dtype=torch.int32, device=dev)
+        d_offsets = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        ctx.encode_blocks(d_in, nb * BLOCK, d_slots, d_sizes)
+        ctx.sync()
+        ctx.timing(True)
+        ctx.encode_blocks(d_in, nb * BLOCK, d_slots, d_sizes)
+        ctx.sync()
+        enc_ms, _ = ctx.kernel_ms(1)
+        ctx.timing(False)
+        tot = int(d_sizes.to(torch.int64).sum().item())
+        d_packed = torch.empty(tot + 64, dtype=torch.uint8, device=dev)
+        ctx.pack(d_slots, d_sizes, nb, d_packed, d_offsets)
+        ctx.sync()
+        del d_slots
+        d_out = torch.empty(nb * BLOCK, dtype=torch.uint8, device=dev)
+        d_out_off = torch.arange(nb, dtype=torch.int64, device=dev) * BLOCK
+        d_out_cap = torch.full((nb,), BLOCK, dtype=torch.int32, device=dev)
+        d_out_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+        d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
+        d_in_off = d_offsets[:nb].contiguous()
+
+        def dec():
+            ctx.decode_blocks(d_packed, d_in_off, d_sizes, nb, d_out, d_out_off, d_out_cap, d_out_len, d_status)
+
+        dec()
+        ctx.sync()
+        ctx.timing(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dec()
+        ctx.sync()
+        t = (time.perf_counter() - t0) / 3
+        dec_ms, _ = ctx.kernel_ms(0)
+        idx_ms, _ = ctx.kernel_ms(4)
+        ctx.timing(False)
+        assert bool(torch.equal(d_out, d_in)), cls
+        u = nb * BLOCK
+        out[cls] = {
+            "decompress_GBps": round(u / t / 1e9, 1),
+            "decode_kernel_ms": round(dec_ms, 3), "index_pass_ms": round(idx_ms, 3),
+            "decode_frac_of_hbm_peak": round((u + tot) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None,
+            "compress_GBps": round(u / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,
+            "compress_kernel_ms": round(enc_ms, 3),
+            "compressed_over_uncompressed": round(tot / u, 3),
+        }
+        del d_in, d_packed, d_out
+    return out
 
 
 def main():
@@ -190,17 +359,29 @@ def main():
     del d_slots
     d_in_off = d_offsets[:nb].contiguous()
 
-    # ---- framed compress of the same bytes (configs[3]), once ---------------------------------------
-    d_fslots = torch.empty(nb * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
-    d_fsizes = torch.empty(nb, dtype=torch.int32, device=dev)
-    ctx.encode_blocks(d_in, nb * BLOCK, d_fslots, d_fsizes, unit=hip.UNIT_FRAME)
-    ctx.sync()
+    # ---- framed compress + uncompress of the same bytes (configs[3]): ONE genuine stream --------------
+    # compressFramed: stream identifier + one chunk per block (CRC32C of every block, encodeFrame in
+    # the encode kernel, contiguous pack); uncompressFramed of that stream: chunk walk, decode, CRC
+    # comparison and verdict on the device.  Stream and output stay in HBM.
+    fcap = hip.max_compressed_len_framed(nb * BLOCK)
+    d_fstream = torch.empty(fcap, dtype=torch.uint8, device=dev)
+    flen = ctx.compress_framed(d_in, nb * BLOCK, d_fstream, fcap)  # warm
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.encode_blocks(d_in, nb * BLOCK, d_fslots, d_fsizes, unit=hip.UNIT_FRAME)
-    ctx.sync()
+    flen = ctx.compress_framed(d_in, nb * BLOCK, d_fstream, fcap)
     t_fenc = time.perf_counter() - t0
-    del d_fslots, d_fsizes
+    d_fout = torch.empty(nb * BLOCK, dtype=torch.uint8, device=dev)
+    st_f = ctx.uncompress_framed(d_fstream, flen, d_fout, nb * BLOCK)  # warm
+    assert st_f == (0, flen, nb * BLOCK), st_f
+    ctx.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st_f = ctx.uncompress_framed(d_fstream, flen, d_fout, nb * BLOCK)
+    t_fdec = time.perf_counter() - t0
+    walk_ms, _ = ctx.kernel_ms(6)
+    ctx.timing(False)
+    assert st_f == (0, flen, nb * BLOCK) and bool(torch.equal(d_fout, d_in)), "framed round trip differs"
+    del d_fstream, d_fout
 
     # ---- the timed hot path: block decompress --------------------------------------------------------
     d_out = torch.empty(nb * BLOCK, dtype=torch.uint8, device=dev)
@@ -243,12 +424,6 @@ def main():
     assert int((d_status != 0).sum().item()) == 0, "decode reported errors"
     assert bool(torch.equal(d_out, d_in)), "decoded bytes differ from the corpus"
 
-    # ---- framed decompress pass (decode + CRC32C verify inputs), configs[3] ---------------------------
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step(crc=d_crc)
-    ctx.sync()
-    t_fdec = time.perf_counter() - t0
     t_fdec = shard.max_over_ranks(dist if world > 1 else None, t_fdec, dev)
 
     # ---- measured copy bandwidth of this box: the second roofline denominator of SURVEY 8(d) -------
@@ -304,14 +479,22 @@ def main():
             },
             "compress_GBps": round(world * u_bytes / t_enc / 1e9, 3),
             "compress_kernel_ms": round(enc_ms, 3),
+            # compress + decompress of the same bytes, one after the other (BASELINE's metric names both)
+            "roundtrip_GBps": round(world * u_bytes / (t_enc + elapsed / args.steps) / 1e9, 3),
+            # one genuine framed stream (10-byte identifier + one chunk per block), stream and output in HBM
             "framed_compress_GBps": round(world * u_bytes / t_fenc / 1e9, 3),
             "framed_decompress_GBps": round(world * u_bytes / t_fdec / 1e9, 3),
+            "framed_chunk_walk_ms": round(walk_ms, 3),
         }
         if world == 1 and not args.no_cpu:
             offs = d_offsets.cpu().numpy()
             sizes = d_sizes.cpu().numpy()
             ns = min(args.cpu_blocks, nb)
             line["cpu_baseline"] = cpu_baseline(corpus, d_in, d_packed, offs, sizes, ns, 10.0)
+            line["config1_alice29"] = config1_alice29(hip)
+            del d_packed, d_out
+            line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 8192))
+            line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy())
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

@@ -672,12 +672,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
   uint32_t *comp_status = nullptr, *comp_len = nullptr, *comp_crc = nullptr, *stored_crc = nullptr;
   FrameScanResult* d_res = nullptr;
   FrameVerdict* d_verdict = nullptr;
-  for (int attempt = 0;; attempt++) {
-    // chunk lists: room for one chunk per KiB of stream at first; a stream of tinier chunks (a data
-    // chunk takes at least 8 bytes) gets lists for the worst case on the second attempt
-    const uint64_t want = attempt == 0 ? n / 1024 + 4096 : n / 8 + 16;
-    if (want > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
-    const size_t cap_l = (size_t)want;
+  auto carve_lists = [&](size_t cap_l) -> int {
     const size_t per_list = cap_l * (8 + 4 + 8 + 4 + 4 + 4 + 8);
     void* base;
     int st = ws_get(c, 19, 2 * per_list + cap_l * 16 + 256, &base);
@@ -700,6 +695,118 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
     stored_crc = (uint32_t*)q, q += cap_l * 4;
     d_res = (FrameScanResult*)q, q += 128;
     d_verdict = (FrameVerdict*)q;
+    return SNAPPY_HIP_OK;
+  };
+  bool have_lists = false;
+  // ---- the chunk walk in parallel (framed_kernels.h): well-formed streams of at least a few MiB ----
+  if (n >= (4u << 20) && n <= 0xffffffffull * 256) {
+    const uint64_t p0 = check_header ? sizeof kFramingHeader : 0;
+    // (slices of at least 1 MiB: a chaser then has a few dozen chunks to chase, and a small stream few chasers)
+    uint64_t slice = ((n + kFrameChasers - 1) / kFrameChasers + 15) & ~15ull;
+    if (slice < (1u << 20)) slice = 1u << 20;
+    void* wbase;
+    int st = ws_get(c, 15, (size_t)kFrameChasers * (sizeof(FrameChase) + kChaserList * 8 + 8) + 256, &wbase);
+    if (st) return st;
+    uint8_t* q = (uint8_t*)wbase;
+    uint64_t* d_lists = (uint64_t*)q;
+    q += (size_t)kFrameChasers * kChaserList * 8;
+    FrameChase* d_chase = (FrameChase*)q;
+    q += (size_t)kFrameChasers * sizeof(FrameChase);
+    uint32_t* d_base = (uint32_t*)q;
+    q += ((size_t)kFrameChasers + 1) * 4;
+    uint32_t* d_first = (uint32_t*)q;
+    q += (size_t)kFrameChasers * 4;
+    q = (uint8_t*)(((uintptr_t)q + 15) & ~(uintptr_t)15);
+    FrameStitch* d_stitch = (FrameStitch*)q;
+    FrameStitch stitch{};
+    {
+      LaunchTimer lt(c, s, 6);
+      hipLaunchKernelGGL(frame_chase_kernel, dim3(kFrameChasers), dim3(64), 0, s, d_in, n, p0, slice, d_chase, d_lists);
+      hipLaunchKernelGGL(frame_stitch_kernel, dim3(1), dim3(1024), 0, s, d_chase, d_lists, n, p0, slice, d_base, d_first,
+                         d_stitch);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&stitch, d_stitch, sizeof stitch, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
+      fprintf(stderr, "FRAME WALK stitch irregular %u chunks %u slice %llu\n", stitch.irregular, stitch.n_chunks,
+              (unsigned long long)slice);
+    if (!stitch.irregular && stitch.n_chunks) {
+      const size_t H = stitch.n_chunks;
+      if ((st = carve_lists(H + 16))) return st;
+      void* fbase;
+      if ((st = ws_get(c, 14, H * (8 + 4 + 4 + 4) + 3 * (H + 1) * 8 + 256, &fbase))) return st;
+      uint8_t* f = (uint8_t*)fbase;
+      uint64_t* d_pos = (uint64_t*)f;
+      f += H * 8;
+      uint64_t* d_out_at = (uint64_t*)f;
+      f += (H + 1) * 8;
+      uint64_t* d_comp_at = (uint64_t*)f;
+      f += (H + 1) * 8;
+      uint64_t* d_stored_at = (uint64_t*)f;
+      f += (H + 1) * 8;
+      uint32_t* d_ulen = (uint32_t*)f;
+      f += H * 4;
+      uint32_t* d_is_comp = (uint32_t*)f;
+      f += H * 4;
+      uint32_t* d_is_stored = (uint32_t*)f;
+      f += H * 4;
+      uint32_t* d_flags = (uint32_t*)f;  // [0] irregular, [1] fast_ok
+      HIP_TRY(hipMemsetAsync(d_flags, 0, 8, s));
+      FrameFillParams fp{};
+      fp.in = d_in;
+      fp.n = n;
+      fp.lists = d_lists;
+      fp.base = d_base;
+      fp.first = d_first;
+      fp.stitch = d_stitch;
+      fp.pos = d_pos;
+      fp.ulen = d_ulen;
+      fp.is_comp = d_is_comp;
+      fp.is_stored = d_is_stored;
+      fp.irregular = d_flags;
+      const uint32_t grid = (uint32_t)((H + 255) / 256);
+      hipLaunchKernelGGL(frame_fill_kernel, dim3(grid), dim3(256), 0, s, fp);
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ulen, (uint64_t)H, (uint64_t)0, d_out_at);
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_comp, (uint64_t)H, (uint64_t)0, d_comp_at);
+      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_stored, (uint64_t)H, (uint64_t)0, d_stored_at);
+      FrameScatterParams xp{};
+      xp.in = d_in;
+      xp.n = n;
+      xp.cap = cap;
+      xp.stitch = d_stitch;
+      xp.irregular = d_flags;
+      xp.pos = d_pos;
+      xp.ulen = d_ulen;
+      xp.is_comp = d_is_comp;
+      xp.is_stored = d_is_stored;
+      xp.out_at = d_out_at;
+      xp.comp_at = d_comp_at;
+      xp.stored_at = d_stored_at;
+      xp.comp = comp;
+      xp.stored = stored;
+      xp.list_cap = (uint32_t)(H + 16);
+      xp.check_header = check_header;
+      xp.res = d_res;
+      xp.fast_ok = d_flags + 1;
+      hipLaunchKernelGGL(frame_scatter_kernel, dim3(grid), dim3(256), 0, s, xp);
+      HIP_TRY(hipGetLastError());
+      uint32_t flags[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      have_lists = flags[1] == 1;
+      if (dbg_env("SNAPPY_HIP_STATS")) fprintf(stderr, "FRAME WALK fill irregular %u fast_ok %u\n", flags[0], flags[1]);
+    }
+  }
+  for (int attempt = 0; !have_lists; attempt++) {  // the serial walk: every stream, every verdict
+    // chunk lists: room for one chunk per KiB of stream at first; a stream of tinier chunks (a data
+    // chunk takes at least 8 bytes) gets lists for the worst case on the second attempt
+    const uint64_t want = attempt == 0 ? n / 1024 + 4096 : n / 8 + 16;
+    if (want > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+    const size_t cap_l = (size_t)want;
+    int st = carve_lists(cap_l);
+    if (st) return st;
     FrameScanParams sp{};
     sp.in = d_in;
     sp.n = n;
