@@ -124,6 +124,12 @@ int snappy_hip_decode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const u
 /* Masked CRC32C of n_units byte ranges d_in[d_off[i] ..+ d_len[i]] into d_crc[i]. */
 int snappy_hip_crc32c_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_off,
                         const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc, void* stream);
+/* uncompress, snappy.nim:84-110, of ONE raw buffer RESIDENT IN HBM (the varint and all) into d_out.
+ * A buffer of several 64 KiB blocks is split on the device and its blocks are decoded in parallel;
+ * streams whose elements straddle block boundaries (foreign encoders) take the serial kernel.
+ * *written is host memory; returns when done. */
+int snappy_hip_uncompress_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
+                            uint64_t cap, uint64_t* written, void* stream);
 /* compressFramed, snappy.nim:130-155, for an input RESIDENT IN HBM: stream identifier + one chunk
  * per 65536-byte slice (encodeFrame, snappy/encoder.nim:385-426) packed into d_out[0 .. *written).
  * cap >= snappy_hip_max_compressed_len_framed(n), else SNAPPY_HIP_BUFFER_TOO_SMALL.  Returns when
@@ -141,7 +147,7 @@ int snappy_hip_uncompress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uin
 /* Average duration in milliseconds of the last timed kernel launches, measured with HIP
  * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
  * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,
- * 3 pack, 4 decode index pass, 5 whole-stream decode pass, 6 framed chunk walk.  Timing is recorded only between
+ * 3 pack, 4 decode index pass, 5 whole-stream decode pass, 6 framed chunk walk, 7 raw-buffer split rounds.  Timing is recorded only between
  * snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */
 int snappy_hip_ctx_timing(snappy_hip_ctx* ctx, int enable);
 double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* ctx, int which, uint64_t* launches);

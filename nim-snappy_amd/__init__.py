@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "snappy_hip_ctx_destroy", "snappy_hip_ctx_sync", "snappy_hip_last_error",
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
-    "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d",
+    "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d", "snappy_hip_uncompress_d",
 ]
 
 
@@ -94,6 +94,8 @@ lib.snappy_hip_uncompress_framed_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, c
                                                ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_uint64),
                                                ctypes.POINTER(ctypes.c_uint64), _vp]
+lib.snappy_hip_uncompress_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
+                                        ctypes.POINTER(ctypes.c_uint64), _vp]
 lib.snappy_hip_ctx_timing.argtypes = [_vp, ctypes.c_int]
 lib.snappy_hip_ctx_kernel_ms.restype = ctypes.c_double
 lib.snappy_hip_ctx_kernel_ms.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
@@ -337,6 +339,14 @@ class Context:
             self._h, _ptr(d_in), n, _ptr(d_out), cap, int(check_header), int(check_integrity),
             ctypes.byref(r), ctypes.byref(w), stream))
         return st, r.value, w.value
+
+    def uncompress(self, d_in, n, d_out, cap, stream=None):
+        """uncompress of ONE raw buffer d_in[0:n] (device) into d_out (device): (status, written)."""
+        _after_torch(stream, d_in, d_out)
+        w = ctypes.c_uint64()
+        st = _check_device(lib.snappy_hip_uncompress_d(self._h, _ptr(d_in), n, _ptr(d_out), cap,
+                                                       ctypes.byref(w), stream))
+        return st, w.value
 
     def timing(self, enable):
         lib.snappy_hip_ctx_timing(self._h, int(enable))

@@ -25,6 +25,7 @@
 #include "encode_kernel.h"
 #include "framed_kernels.h"
 #include "index_kernel.h"
+#include "split_kernels.h"
 
 using namespace snappy_hip;
 
@@ -1215,19 +1216,105 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
   return SNAPPY_HIP_OK;
 }
 
+// Block starts of one raw buffer by the speculative parallel walk of split_kernels.h.  d_tags = the
+// tag stream (behind the varint) in device memory.  Returns 0 (d_blk[k] = stream position of block
+// k's first element for every k), a status > 0 (the walk saw the whole stream: its verdict stands), or
+// -1: not applicable (no fixed point within the round limit, an element straddles a block boundary).
+int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
+                      uint32_t* d_blk, hipStream_t s) {
+  constexpr int kMaxRounds = 48;
+  const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
+  void* base;
+  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
+  if (st) return st;
+  uint8_t* q = (uint8_t*)base;
+  unsigned long long* nxt[2];
+  nxt[0] = (unsigned long long*)q, q += (size_t)nseg * 8;
+  nxt[1] = (unsigned long long*)q, q += (size_t)nseg * 8;
+  uint64_t* out_at = (uint64_t*)q;
+  q += ((size_t)nseg + 1) * 8;
+  uint32_t* prev = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* outb = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* changed = (uint32_t*)q;  // one block of 128 words per round: [0] entries changed, [64] a claim cut
+  q += 128 * 4 * 0;                  // (rounds share the block: each round's words are read before the next look)
+  q += 128 * 4;
+  uint32_t* flags = (uint32_t*)q;
+  HIP_TRY(hipMemsetAsync(nxt[0], 0xff, (size_t)nseg * 16, s));  // both buffers: nobody has claimed anything
+  HIP_TRY(hipMemsetAsync(prev, 0xff, (size_t)nseg * 4, s));
+  HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4 + 16, s));
+  SplitParams sp{};
+  sp.in = d_tags;
+  sp.n = n_tags;
+  sp.nseg = nseg;
+  sp.prev = prev;
+  sp.outb = outb;
+  sp.flags = flags;
+  sp.out_at = out_at;
+  sp.blk_in = d_blk;
+  const uint32_t grid = (nseg + 255) / 256;
+  uint32_t h_changed[128];
+  int r = 0;
+  bool converged = false;
+  while (r < kMaxRounds && !converged) {
+    const int r_hi = r + (r == 0 ? 3 : 4) < kMaxRounds ? r + (r == 0 ? 3 : 4) : kMaxRounds;  // a few rounds per look
+    for (; r < r_hi; r++) {
+      sp.nxt_in = nxt[r & 1];
+      sp.nxt_out = nxt[(r + 1) & 1];
+      sp.changed = changed;
+      sp.locate = 0;
+      if (r + 1 == r_hi) HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4, s));  // the look reads the last round's words
+      LaunchTimer lt(c, s, 7);
+      hipLaunchKernelGGL(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_changed, changed, sizeof h_changed, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    converged = h_changed[0] == 0;
+    if (converged && h_changed[64]) return -1;  // a claim was cut short in the round that changed nothing
+    // (streams of long literals back to back -- incompressible data -- converge one literal per round:
+    // not worth the rounds; the serial walk takes them)
+    if (!converged && r >= 7 && h_changed[0] > nseg / 64) r = kMaxRounds;
+    if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
+      fprintf(stderr, "SPLIT round %d changed %u cut %u\n", r, h_changed[0], h_changed[64]);
+    }
+  }
+  if (!converged) return -1;
+  // (rounds after the first unchanged one changed nothing either: prev and outb are the fixed point's)
+  hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
+  uint64_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108 (or an invalid element cut the walk short)
+  (void)nblk;
+  sp.locate = 1;
+  hipLaunchKernelGGL(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+  HIP_TRY(hipGetLastError());
+  uint32_t h_flags[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_flags[1]) return SNAPPY_HIP_INVALID_INPUT;
+  if (h_flags[2]) return -1;
+  return SNAPPY_HIP_OK;
+}
+
 // uncompress() of a raw buffer that decodes to more than one 64 KiB block.  The stream has no block
 // delimiters (snappy.nim:49-62), so one wave first walks it and records where every 64 KiB of
 // output starts (index_units_kernel<true>); the blocks are then decoded in parallel like
 // independent units.  Returns -1 when that does not apply (an element or a copy crosses a 64 KiB
 // output boundary, possible with foreign encoders): the caller then uses the serial kernel.
+// (d_in_res / d_out_res: the buffer / the output are resident in device memory already)
 int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32_t hdr, uint64_t len,
-                          uint8_t* out, size_t* written) {
+                          uint8_t* out, size_t* written, const uint8_t* d_in_res = nullptr,
+                          uint8_t* d_out_res = nullptr) {
   if (len > (1ull << 31) || n > (1ull << 31)) return -1;
   int st;
   const size_t nblk = (size_t)((len + kMaxBlockLen - 1) / kMaxBlockLen);
-  void *d_in, *d_out, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_blk, *d_one;
-  if ((st = ws_get(c, 0, n + 64, &d_in))) return st;
-  if ((st = ws_get(c, 4, len + 64, &d_out))) return st;
+  void *d_in = const_cast<uint8_t*>(d_in_res), *d_out = d_out_res, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_blk,
+       *d_one;
+  if (!d_in_res && (st = ws_get(c, 0, n + 64, &d_in))) return st;
+  if (!d_out_res && (st = ws_get(c, 4, len + 64, &d_out))) return st;
   if ((st = ws_get(c, 3, nblk * 8, &d_io))) return st;
   if ((st = ws_get(c, 2, nblk * 4, &d_il))) return st;
   if ((st = ws_get(c, 5, nblk * 8, &d_oo))) return st;
@@ -1237,8 +1324,14 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   if ((st = ws_get(c, 9, (nblk + 1) * 4, &d_blk))) return st;
   if ((st = ws_get(c, 10, 64, &d_one))) return st;
   hipStream_t s = c->stream;
-  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  if (!d_in_res) HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+  // first the speculative parallel walk (split_kernels.h); the one-workgroup walk below is its fallback
+  const int spec = dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT")
+                       ? -1
+                       : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk, s);
+  if (spec > 0) return spec;
+  if (spec < 0) HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
   // the splitter's one unit: [in_off u64 | in_len u32 | out_cap u32 | out_len u32 | status u32]
   struct {
     uint64_t in_off;
@@ -1261,7 +1354,7 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
     HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
     ip.idx = (uint32_t*)d_sdbg;
   }
-  hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
+  if (spec < 0) hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
   if (d_sdbg) {
     unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, d_sdbg, 64, hipMemcpyDeviceToHost, s));
@@ -1275,8 +1368,10 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(blk.data(), d_blk, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
-  if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
+  if (spec < 0) {
+    if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
+    if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
+  }
   blk[0] = 0;
   blk[nblk] = (uint32_t)(n - hdr);
   std::vector<uint64_t> io(nblk), oo(nblk);
@@ -1303,12 +1398,58 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   HIP_TRY(hipStreamSynchronize(s));
   for (size_t k = 0; k < nblk; k++)
     if (stv[k] != kOk || olv[k] != oc[k]) return -1;  // e.g. a copy that reaches into an earlier block
-  HIP_TRY(hipMemcpy(out, d_out, len, hipMemcpyDeviceToHost));
+  if (!d_out_res) HIP_TRY(hipMemcpy(out, d_out, len, hipMemcpyDeviceToHost));
   *written = (size_t)len;
   return SNAPPY_HIP_OK;
 }
 
 }  // namespace
+
+// uncompress (snappy.nim:84-110) of ONE raw buffer resident in HBM into d_out (device).  A buffer of
+// several blocks is split on the device (split_kernels.h) and its blocks are decoded in parallel;
+// where that does not apply (a foreign encoder's elements straddle block boundaries) it is decoded
+// by the serial whole-stream kernel.  *written (host): bytes produced.  Returns when done.
+extern "C" int snappy_hip_uncompress_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
+                                       uint64_t cap, uint64_t* written, void* stream) {
+  *written = 0;
+  DeviceGuard guard(c->device);
+  hipStream_t s = pick_stream(c, stream);
+  if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;
+  uint8_t hb[8] = {0};
+  const size_t hn = n < 8 ? (size_t)n : 8;
+  if (hn) HIP_TRY(hipMemcpyAsync(hb, d_in, hn, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  uint64_t len;
+  const int hdr = varint_decode(hb, hn, 32, &len);  // snappy.nim:92-94
+  if (hdr <= 0) return SNAPPY_HIP_INVALID_INPUT;
+  if (cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
+  if (len > kMaxBlockLen && s == c->stream) {
+    size_t w = 0;
+    const int rs = uncompress_split_host(c, nullptr, (size_t)n, (uint32_t)hdr, len, nullptr, &w, d_in, d_out);
+    if (rs >= 0) {
+      *written = w;
+      return rs;
+    }
+  }
+  // one RAW unit: the block kernels, or the serial whole-stream kernel for more than 64 KiB
+  void* d_u;
+  int st = ws_get(c, 12, 64, &d_u);
+  if (st) return st;
+  struct {
+    uint64_t in_off, out_off;
+    uint32_t in_len, out_cap, out_len, status;
+  } u = {0, 0, (uint32_t)n, (uint32_t)len, 0, 0};
+  HIP_TRY(hipMemcpyAsync(d_u, &u, sizeof u, hipMemcpyHostToDevice, s));
+  uint8_t* q = (uint8_t*)d_u;
+  if ((st = decode_d(c, d_in, (const uint64_t*)q, (const uint32_t*)(q + 16), 1, kUnitRaw, nullptr, d_out,
+                     (const uint64_t*)(q + 8), (const uint32_t*)(q + 20), (uint32_t*)(q + 24), (uint32_t*)(q + 28), true, s)))
+    return st;
+  HIP_TRY(hipMemcpyAsync(&u, d_u, sizeof u, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (u.status != kOk) return (int)u.status;
+  *written = u.out_len;
+  return SNAPPY_HIP_OK;
+}
 
 extern "C" int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,
                                    size_t* written) {

@@ -1,0 +1,127 @@
+// split_kernels.h -- where do the 64 KiB blocks of ONE raw Snappy buffer start?
+//
+// uncompress() of a buffer that decodes to more than one block (snappy.nim:84-110): the stream has
+// one varint and no block delimiters (snappy.nim:49-62), so block k's first element can only be
+// found by walking the tags (decoder.nim:39-109) -- a chain through the whole stream.  The chain is
+// broken up by guessing: the stream is cut into segments of kSplitSeg bytes, one LANE per segment
+// walks the elements of its segment from where it believes the chain enters it, and tells the
+// segments behind it where the chain leaves.  Segment 0's entry is known; every other segment
+// starts with the guess "at my first byte".  A walk that starts wrong falls into step with the real
+// chain after a few elements (elements are short), so after a few rounds most segments are right,
+// and the rounds repeat until no entry changes -- which, since segment 0 is right and every segment
+// takes its entry from the EARLIEST segment that claims it, is exactly the state where all are right
+// (an element that jumps over segments, a long literal, writes the entry of every segment it
+// covers).  Then a prefix sum over the segments' output bytes places them in the output, and a last
+// walk records, for every 64 KiB boundary, the stream position of the element that starts there --
+// or that an element straddles it (a foreign encoder: the caller falls back to the serial walk).
+// All input-side checks of decodeAllTags are made by the walk (decode_element, index_kernel.h).
+#pragma once
+
+#include "common.h"
+#include "index_kernel.h"
+
+namespace snappy_hip {
+
+constexpr uint32_t kSplitSeg = 1024;     // stream bytes per lane
+// Segments one element may claim: a literal of a whole 64 KiB block and its length bytes.  (A walk
+// that starts wrong reads payload bytes as tags, and one byte in fifty is the tag of a literal with
+// explicit length: unbounded, such claims would keep overriding the right ones far downstream.
+// Streams with longer literals converge slowly or not at all within the round limit: serial walk.)
+constexpr uint32_t kSplitMaxCover = 65536 / kSplitSeg + 1;
+
+struct SplitParams {
+  const uint8_t* in;      // the tag stream (behind the varint)
+  uint32_t n;             // its length
+  uint32_t nseg;
+  const unsigned long long* nxt_in;  // [nseg] (writer segment << 32) | entry position; ~0: nobody claimed it
+  unsigned long long* nxt_out;
+  uint32_t* prev;         // [nseg] the entry used in the previous round
+  uint32_t* outb;         // [nseg] output bytes of the elements that start in the segment
+  uint32_t* changed;      // entries that changed this round (one counter per round); [64]: a claim was cut short this round
+  uint32_t* flags;        // [1] invalid element met, [2] an element straddles a 64 KiB boundary of the output
+  // locate pass
+  const uint64_t* out_at; // [nseg + 1] exclusive prefix sum of outb
+  uint32_t* blk_in;       // [nblk] stream position where output block k starts
+  int locate;
+};
+
+// the element at p: false = invalid (decoder.nim:54-57, :67-68, :77-79, truncated copies)
+__device__ __forceinline__ bool split_element(const uint8_t* in, uint32_t n, uint32_t p, uint32_t* L, uint32_t* size) {
+  uint32_t tag, b14;
+  if (p + 8 <= n) {
+    const uint32_t w0 = ld32u(in + p), w1 = ld32u(in + p + 4);
+    tag = w0 & 0xff;
+    b14 = (w0 >> 8) | (w1 << 24);
+  } else {
+    uint32_t b[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < 5 && p + i < n; i++) b[i] = in[p + i];
+    tag = b[0];
+    b14 = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24);
+  }
+  return decode_element_bf(tag, b14, n - p - 1, L, size);
+}
+
+__global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.nseg) return;
+  const uint32_t seg_lo = s * kSplitSeg;
+  const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
+  uint32_t e = seg_lo;  // the guess
+  if (p.locate) {
+    e = p.prev[s];      // (the entries of the last round, which changed nothing)
+  } else if (s == 0) {
+    e = 0;
+  } else {
+    const unsigned long long k = p.nxt_in[s];
+    if (k != ~0ull) e = (uint32_t)k;
+  }
+  if (!p.locate) {
+    const uint64_t ch = __ballot(e != p.prev[s]);  // (one atomic per wave, not per lane)
+    if (ch && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(ch)) atomicAdd(p.changed, (uint32_t)__builtin_popcountll(ch));
+    p.prev[s] = e;
+    const_cast<unsigned long long*>(p.nxt_in)[s] = ~0ull;  // (mine to reset: this buffer is written again next round)
+  }
+  uint32_t pos = e, out = 0;
+  uint64_t op = p.locate ? p.out_at[s] : 0;
+  bool bad = false;
+  bool suspect = false;  // met an element no block encoder writes (copy4, literal tags 62/63: encoder.nim:44-125)
+  while (pos < seg_hi) {
+    uint32_t L, size;
+    if (!split_element(p.in, p.n, pos, &L, &size)) {
+      bad = true;
+      break;
+    }
+    {
+      const uint32_t tg = p.in[pos];
+      suspect = suspect || (tg & 3) == 3 || ((tg & 3) == 0 && (tg >> 2) >= 62);
+    }
+    if (p.locate) {
+      if ((op & 0xffffu) == 0) p.blk_in[op >> 16] = pos;
+      else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
+      op += L;
+    }
+    out += L;
+    pos += size;
+  }
+  if (p.locate) {
+    if (bad && e < seg_hi) p.flags[1] = 1;
+    return;
+  }
+  p.outb[s] = e < seg_hi ? out : 0;
+  if (bad || e >= seg_hi) return;  // (a segment the chain passes over claims nothing)
+  // the chain leaves at pos: that is the entry of every segment up to the one that holds it
+  uint32_t t_hi = pos / kSplitSeg;
+  t_hi = t_hi < p.nseg - 1 ? t_hi : p.nseg - 1;
+  const uint32_t t_all = t_hi;
+  t_hi = t_hi < s + kSplitMaxCover ? t_hi : s + kSplitMaxCover;
+  // A walk that started wrong reads payload as tags; one payload byte in four looks like a copy4.  Such a
+  // walk claims its neighbour only: its far claims would override right ones downstream, round after round.
+  if (suspect) t_hi = t_hi < s + 1 ? t_hi : s + 1;
+  // (the "no entry changes = all entries right" argument needs every claim of a RIGHT walk complete; in
+  // the right state only right walks exist, so a cut claim in the last round means: do not trust it)
+  if (t_hi != t_all) p.changed[64] = 1;
+  const unsigned long long key = ((unsigned long long)s << 32) | pos;
+  for (uint32_t t = s + 1; t <= t_hi; t++) atomicMin(&p.nxt_out[t], key);
+}
+
+}  // namespace snappy_hip
