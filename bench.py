@@ -167,7 +167,7 @@ def config1_alice29(hip):
     }
 
 
-def host_api_rates(hip, src_np):
+def host_api_rates(hip, src_np, ctx=None, dev=None):
     """The host-buffer C ABI end to end (PCIe copies included; never `value`): GB/s of uncompressed
     bytes for one call over src_np, and two host threads at once."""
     import ctypes
@@ -216,6 +216,20 @@ def host_api_rates(hip, src_np):
 
     res["uncompress_GBps"] = round(n / best(ur, reps=1) / 1e9, 2)
     assert w.value == n and np.array_equal(back, src_np)
+    if ctx is not None:  # the same raw multi-block buffer resident in HBM (snappy_hip_uncompress_d), and 64 MiB of it
+        for tag, nblk in (("raw_buffer_uncompress_d_GBps", n // BLOCK), ("raw_buffer_64MiB_uncompress_d_GBps", 1024)):
+            part = src_np[:nblk * BLOCK]
+            rr = np.empty(hip.max_compressed_len(part.size), dtype=np.uint8)
+            assert lib.snappy_hip_compress(C(part), part.size, P(rr), rr.size, ctypes.byref(w)) == 0
+            d_raw = torch.from_numpy(rr[:w.value]).to(dev)
+            d_back = torch.empty(part.size, dtype=torch.uint8, device=dev)
+            rl = int(w.value)
+
+            def ud():
+                assert ctx.uncompress(d_raw, rl, d_back, part.size) == (0, part.size)
+
+            res[tag] = round(part.size / best(ud) / 1e9, 2)
+            assert np.array_equal(d_back.cpu().numpy(), part)
     half = n // 2
     outs = [np.empty(cap, dtype=np.uint8) for _ in range(2)]
     ws = [ctypes.c_size_t(), ctypes.c_size_t()]
@@ -494,7 +508,7 @@ def main():
             line["config1_alice29"] = config1_alice29(hip)
             del d_packed, d_out
             line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 8192))
-            line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy())
+            line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy(), ctx, dev)
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

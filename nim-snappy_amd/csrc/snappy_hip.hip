@@ -1222,10 +1222,10 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // -1: not applicable (no fixed point within the round limit, an element straddles a block boundary).
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s) {
-  constexpr int kMaxRounds = 48;
+  constexpr int kMaxRounds = 40;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
   void* base;
-  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
+  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
   unsigned long long* nxt[2];
@@ -1236,6 +1236,10 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   uint32_t* prev = (uint32_t*)q;
   q += (size_t)nseg * 4;
   uint32_t* outb = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* memo = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* reached = (uint32_t*)q;
   q += (size_t)nseg * 4;
   uint32_t* changed = (uint32_t*)q;  // one block of 128 words per round: [0] entries changed, [64] a claim cut
   q += 128 * 4 * 0;                  // (rounds share the block: each round's words are read before the next look)
@@ -1250,6 +1254,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.nseg = nseg;
   sp.prev = prev;
   sp.outb = outb;
+  sp.memo = memo;
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;
@@ -1268,20 +1273,22 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
       LaunchTimer lt(c, s, 7);
       hipLaunchKernelGGL(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
     }
+    // is this the right state already?  (split_check_kernel: a proof that does not depend on the rounds)
+    HIP_TRY(hipMemsetAsync(reached, 0, (size_t)nseg * 4, s));
+    HIP_TRY(hipMemsetAsync(changed + 64, 0, 4, s));
+    hipLaunchKernelGGL(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 0);
+    hipLaunchKernelGGL(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_changed, changed, sizeof h_changed, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    converged = h_changed[0] == 0;
-    if (converged && h_changed[64]) return -1;  // a claim was cut short in the round that changed nothing
-    // (streams of long literals back to back -- incompressible data -- converge one literal per round:
-    // not worth the rounds; the serial walk takes them)
-    if (!converged && r >= 7 && h_changed[0] > nseg / 64) r = kMaxRounds;
-    if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
-      fprintf(stderr, "SPLIT round %d changed %u cut %u\n", r, h_changed[0], h_changed[64]);
-    }
+    converged = h_changed[64] == 0;
+    // (streams of long literals back to back -- incompressible data -- settle one literal per round:
+    // past a point the serial walk is the better deal)
+    if (!converged && r >= 15 && h_changed[0] > nseg / 32) r = kMaxRounds;
+    if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
+      fprintf(stderr, "SPLIT round %d changed %u check %s\n", r, h_changed[0], converged ? "ok" : "no");
   }
   if (!converged) return -1;
-  // (rounds after the first unchanged one changed nothing either: prev and outb are the fixed point's)
   hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));

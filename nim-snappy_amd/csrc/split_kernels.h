@@ -28,6 +28,7 @@ constexpr uint32_t kSplitSeg = 1024;     // stream bytes per lane
 // explicit length: unbounded, such claims would keep overriding the right ones far downstream.
 // Streams with longer literals converge slowly or not at all within the round limit: serial walk.)
 constexpr uint32_t kSplitMaxCover = 65536 / kSplitSeg + 1;
+constexpr uint32_t kSplitClean = 16;  // native elements in a row that make a walk trusted (see the kernel)
 
 struct SplitParams {
   const uint8_t* in;      // the tag stream (behind the varint)
@@ -35,9 +36,10 @@ struct SplitParams {
   uint32_t nseg;
   const unsigned long long* nxt_in;  // [nseg] (writer segment << 32) | entry position; ~0: nobody claimed it
   unsigned long long* nxt_out;
-  uint32_t* prev;         // [nseg] the entry used in the previous round
+  uint32_t* prev;         // [nseg] the entry used in the previous round (bit 31: it was a claimed one)
   uint32_t* outb;         // [nseg] output bytes of the elements that start in the segment
-  uint32_t* changed;      // entries that changed this round (one counter per round); [64]: a claim was cut short this round
+  uint32_t* memo;         // [nseg] the last walk's exit ([0:31), all ones = invalid element) and trust (bit 31)
+  uint32_t* changed;      // entries that changed this round
   uint32_t* flags;        // [1] invalid element met, [2] an element straddles a 64 KiB boundary of the output
   // locate pass
   const uint64_t* out_at; // [nseg + 1] exclusive prefix sum of outb
@@ -67,61 +69,105 @@ __global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
   const uint32_t seg_lo = s * kSplitSeg;
   const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
   uint32_t e = seg_lo;  // the guess
+  bool claimed = s == 0;
   if (p.locate) {
-    e = p.prev[s];      // (the entries of the last round, which changed nothing)
+    e = p.prev[s] & 0x7fffffffu;  // (the entries of the last round)
   } else if (s == 0) {
     e = 0;
   } else {
     const unsigned long long k = p.nxt_in[s];
-    if (k != ~0ull) e = (uint32_t)k;
+    if (k != ~0ull) {
+      e = (uint32_t)k;
+      claimed = true;
+    }
   }
+  bool same = false;
   if (!p.locate) {
-    const uint64_t ch = __ballot(e != p.prev[s]);  // (one atomic per wave, not per lane)
+    // (bit 31: the entry was claimed -- a walk from a claimed entry starts trusted, so a guess that
+    // turns into a claim of the same position is a different walk)
+    const uint32_t pw = e | (claimed ? 0x80000000u : 0u);
+    same = pw == p.prev[s];
+    const uint64_t ch = __ballot(!same);  // (one atomic per wave, not per lane)
     if (ch && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(ch)) atomicAdd(p.changed, (uint32_t)__builtin_popcountll(ch));
-    p.prev[s] = e;
+    p.prev[s] = pw;
     const_cast<unsigned long long*>(p.nxt_in)[s] = ~0ull;  // (mine to reset: this buffer is written again next round)
   }
-  uint32_t pos = e, out = 0;
+  // Trust: a walk that started wrong reads payload bytes as tags, and one payload byte in four looks
+  // like a copy4 -- an element no block encoder writes (nor literal tags 62/63: encoder.nim:44-125).
+  // A walk may claim segments beyond its neighbour (the target of a long literal) only with kSplitClean
+  // "native" elements in a row behind it: its far claims would otherwise keep overriding right ones
+  // downstream.  A walk from a claimed entry starts trusted, one from a guess does not.
+  uint32_t pos = e, out = 0, clean = claimed ? kSplitClean : 0;
   uint64_t op = p.locate ? p.out_at[s] : 0;
   bool bad = false;
-  bool suspect = false;  // met an element no block encoder writes (copy4, literal tags 62/63: encoder.nim:44-125)
-  while (pos < seg_hi) {
-    uint32_t L, size;
-    if (!split_element(p.in, p.n, pos, &L, &size)) {
-      bad = true;
-      break;
-    }
-    {
+  if (same) {  // same entry as last round: same walk, same result
+    const uint32_t m = p.memo[s];
+    pos = m & 0x7fffffffu;
+    clean = (m >> 31) ? kSplitClean : 0;
+    bad = pos == 0x7fffffffu;
+  } else {
+    while (pos < seg_hi) {
+      uint32_t L, size;
+      if (!split_element(p.in, p.n, pos, &L, &size)) {
+        bad = true;
+        break;
+      }
+      if (p.locate) {
+        if ((op & 0xffffu) == 0) p.blk_in[op >> 16] = pos;
+        else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
+        op += L;
+      }
       const uint32_t tg = p.in[pos];
-      suspect = suspect || (tg & 3) == 3 || ((tg & 3) == 0 && (tg >> 2) >= 62);
+      clean = ((tg & 3) == 3 || ((tg & 3) == 0 && (tg >> 2) >= 62)) ? 0 : clean + 1;
+      out += L;
+      pos += size;
     }
-    if (p.locate) {
-      if ((op & 0xffffu) == 0) p.blk_in[op >> 16] = pos;
-      else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
-      op += L;
-    }
-    out += L;
-    pos += size;
   }
   if (p.locate) {
     if (bad && e < seg_hi) p.flags[1] = 1;
     return;
   }
-  p.outb[s] = e < seg_hi ? out : 0;
+  if (!same) {
+    p.outb[s] = e < seg_hi ? out : 0;
+    p.memo[s] = bad ? 0x7fffffffu : (pos | (clean >= kSplitClean ? 0x80000000u : 0u));
+  }
   if (bad || e >= seg_hi) return;  // (a segment the chain passes over claims nothing)
   // the chain leaves at pos: that is the entry of every segment up to the one that holds it
   uint32_t t_hi = pos / kSplitSeg;
   t_hi = t_hi < p.nseg - 1 ? t_hi : p.nseg - 1;
   const uint32_t t_all = t_hi;
   t_hi = t_hi < s + kSplitMaxCover ? t_hi : s + kSplitMaxCover;
-  // A walk that started wrong reads payload as tags; one payload byte in four looks like a copy4.  Such a
-  // walk claims its neighbour only: its far claims would override right ones downstream, round after round.
-  if (suspect) t_hi = t_hi < s + 1 ? t_hi : s + 1;
-  // (the "no entry changes = all entries right" argument needs every claim of a RIGHT walk complete; in
-  // the right state only right walks exist, so a cut claim in the last round means: do not trust it)
-  if (t_hi != t_all) p.changed[64] = 1;
+  if (clean < kSplitClean) t_hi = t_hi < s + 1 ? t_hi : s + 1;
+  (void)t_all;
   const unsigned long long key = ((unsigned long long)s << 32) | pos;
   for (uint32_t t = s + 1; t <= t_hi; t++) atomicMin(&p.nxt_out[t], key);
+}
+
+// Is the state the right one?  Independent of how it was reached: the walked segments must form ONE
+// chain -- each walk starts exactly where another one ended (or at the stream's first byte), every walk
+// is started by one, the last one ends at the stream's end.  Such a chain IS the sequential parse.
+// step 0: every walk marks the segment its exit lies in, and checks that segment's entry;
+// step 1: every walk but segment 0's must have been marked.  fail[0] != 0: not (yet) the right state.
+__global__ __launch_bounds__(256) void split_check_kernel(SplitParams p, uint32_t* reached, uint32_t* fail, int step) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.nseg) return;
+  const uint32_t seg_hi = (s + 1) * kSplitSeg < p.n ? (s + 1) * kSplitSeg : p.n;
+  const uint32_t e = p.prev[s] & 0x7fffffffu;
+  if (e >= seg_hi) return;  // the chain passes over this segment
+  if (step == 0) {
+    const uint32_t m = p.memo[s] & 0x7fffffffu;
+    if (m == 0x7fffffffu || m > p.n) {
+      fail[0] = 1;  // an invalid element: for the serial walk to judge
+    } else if (m < p.n) {
+      const uint32_t t = m / kSplitSeg;
+      if ((p.prev[t] & 0x7fffffffu) != m) fail[0] = 1;
+      reached[t] = 1;
+    }
+  } else if (s != 0 && !reached[s]) {
+    fail[0] = 1;
+  } else if (s == 0 && e != 0) {
+    fail[0] = 1;
+  }
 }
 
 }  // namespace snappy_hip
