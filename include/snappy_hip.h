@@ -16,9 +16,12 @@
  * (CodecError / FrameError, snappy/codec.nim:55-64).
  *
  * Thread safety: like the reference (all `func`, no globals) every call is re-entrant.  The
- * host-buffer calls serialise on one process-wide device context; callers that want
- * concurrency create their own context and use the *_ctx / device entry points.  One context
- * serves one thread (and one stream) at a time: it owns scratch buffers that its calls reuse.
+ * host-buffer calls take a context from a process-wide pool (one per concurrent call; created on
+ * demand on the GPU SNAPPY_HIP_DEVICE names, default 0) and run side by side; large inputs go in
+ * batches on up to three worker threads so that upload, kernels and download overlap.  An explicit
+ * context (snappy_hip_ctx_create) serves one thread (and one stream) at a time: it owns scratch
+ * buffers that its calls reuse.  Every entry point makes its context's device current for the
+ * call and restores the caller's.
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
@@ -80,6 +83,12 @@ int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* out, size_t
                                size_t* written);
 
 /* ---- device-resident batch API (what the GPU needs; the reference has no counterpart) ------
+ * Memory the kernels touch: they WRITE exactly the bytes of the ranges documented as outputs.  They
+ * READ input ranges with 16-byte loads at 16-byte-ALIGNED addresses, i.e. up to 15 bytes in front of a
+ * unit's first byte and behind its last byte, inside the aligned 16-byte lines that hold those two
+ * bytes.  Such a line always holds a valid byte and never crosses a page, so a unit may lie flush
+ * against either end of an allocation of exactly its size (tests/test_gpu_batch.py places units so);
+ * the extra bytes are never interpreted.  No padding is required of the caller.
  * All `d_` pointers are DEVICE memory of the context's GPU.  `stream` is a hipStream_t (NULL =
  * the context's own stream).  Calls enqueue work and return; use snappy_hip_ctx_sync() or
  * your own stream synchronisation before reading results.  Block i of a batch is independent:

@@ -55,7 +55,7 @@ struct Decode2Params {
   const uint32_t* in_len;
   uint8_t* out;
   const uint64_t* out_off;
-  const uint32_t* out_len;  // from the index pass
+  uint32_t* out_len;  // from the index pass (set to 0 here for a unit this pass rejects)
   uint32_t* status;
   const uint64_t* idx_off;  // nullptr: u * idx_stride
   uint64_t idx_stride;
@@ -803,7 +803,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 
   // ---- flush ------------------------------------------------------------------------------------
   if (s_err) {
-    if (tid == 0) prm.status[u] = (s_err & 1) ? kInvalidInput : kNeedsOnePass;
+    if (tid == 0) {
+      prm.status[u] = (s_err & 1) ? kInvalidInput : kNeedsOnePass;
+      if (s_err & 1) prm.out_len[u] = 0;  // (a failed unit reports no bytes, like the one-pass kernel)
+    }
     return;
   }
   if (SNAPPY_DBG(prm) & 8) return;

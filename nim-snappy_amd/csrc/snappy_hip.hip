@@ -50,6 +50,13 @@ inline const char* dbg_env(const char* name) { return getenv(name); }
 inline const char* dbg_env(const char*) { return nullptr; }
 #endif
 
+// every launch is checked where it is made
+#define LAUNCH(...)                   \
+  do {                                \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+    HIP_TRY(hipGetLastError());       \
+  } while (0)
+
 constexpr uint32_t kSlotStride = 76800;  // >= 8 + 3 + 76490, multiple of 256
 const uint8_t kFramingHeader[10] = {0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59};
 
@@ -172,9 +179,9 @@ int launch_order(snappy_hip_ctx* c, const uint32_t* d_keys, uint64_t n, int mode
   uint32_t* counts = perm + n;
   HIP_TRY(hipMemsetAsync(counts, 0, kOrderBuckets * 4, s));
   const uint32_t gb = (uint32_t)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256);
-  hipLaunchKernelGGL(order_count_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts);
-  hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, s, counts);
-  hipLaunchKernelGGL(order_scatter_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts, perm);
+  LAUNCH(order_count_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts);
+  LAUNCH(order_scan_kernel, dim3(1), dim3(64), 0, s, counts);
+  LAUNCH(order_scatter_kernel, dim3(gb), dim3(256), 0, s, d_keys, n, mode, counts, perm);
   *d_perm = perm;
   return SNAPPY_HIP_OK;
 }
@@ -341,7 +348,7 @@ extern "C" int snappy_hip_crc32c_d(snappy_hip_ctx* c, const uint8_t* d_in, const
   hipStream_t s = pick_stream(c, stream);
   {
     LaunchTimer lt(c, s, 2);
-    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, p);
+    LAUNCH(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, p);
   }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
@@ -362,7 +369,7 @@ int crc_fixed_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t total_len, uint
   p.block_len = block_len;
   {
     LaunchTimer lt(c, s, 2);
-    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)nb), dim3(kCrcThreads), 0, s, p);
+    LAUNCH(crc32c_units_kernel, dim3((uint32_t)nb), dim3(kCrcThreads), 0, s, p);
   }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
@@ -407,7 +414,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
     void *d_sk, *d_perm;
     int st = ws_get(c, 16, nb * 8 + kOrderBuckets * 4, &d_sk);
     if (st) return st;
-    hipLaunchKernelGGL(encode_sketch_kernel, dim3((uint32_t)nb), dim3(64), 0, s, d_in, total_len, block_len, nb,
+    LAUNCH(encode_sketch_kernel, dim3((uint32_t)nb), dim3(64), 0, s, d_in, total_len, block_len, nb,
                        (uint32_t*)d_sk);
     if ((st = launch_order(c, (const uint32_t*)d_sk, nb, kOrderBySketch, 16, nb * 4, s, &d_perm))) return st;
     p.order = (const uint32_t*)d_perm;
@@ -420,7 +427,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   }
   {
     LaunchTimer lt(c, s, 1);
-    hipLaunchKernelGGL(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
+    LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
                        dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
   }
   if (d_estats) {
@@ -443,10 +450,10 @@ extern "C" int snappy_hip_pack_d(snappy_hip_ctx* c, const uint8_t* d_slots, uint
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
   LaunchTimer lt(c, s, 3);
-  hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_sizes, n_blocks, base,
+  LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_sizes, n_blocks, base,
                      d_offsets);
   if (n_blocks)
-    hipLaunchKernelGGL(gather_slots_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, s, d_slots,
+    LAUNCH(gather_slots_kernel, dim3((uint32_t)n_blocks), dim3(256), 0, s, d_slots,
                        slot_stride, d_sizes, d_offsets, n_blocks, d_out);
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
@@ -477,7 +484,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   void* d_done = nullptr;  // per unit: the indexed decode kernel has written its CRC
   if (v1) {
     LaunchTimer lt(c, s, 0);
-    hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+    LAUNCH(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
   } else {
     // v2: index pass (where do elements start) + indexed block decode
     const uint64_t stride = kMaxRegionsPerUnit;
@@ -489,9 +496,9 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       // many units: compact index, sized by a scan of the per-unit region counts
       if ((st = ws_get(c, 11, n_units * 4, &d_cnt))) return st;
       if ((st = ws_get(c, 12, (n_units + 1) * 8, &d_ioff))) return st;
-      hipLaunchKernelGGL(region_counts_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256),
+      LAUNCH(region_counts_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256),
                          0, s, d_in_len, n_units, (uint32_t*)d_cnt);
-      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s,
+      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s,
                          (const uint32_t*)d_cnt, n_units, (uint64_t)0, (uint64_t*)d_ioff);
       uint64_t total = 0;
       HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)d_ioff + n_units, 8, hipMemcpyDeviceToHost, s));
@@ -547,12 +554,12 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     }
     {
       LaunchTimer lt(c, s, 4);
-      hipLaunchKernelGGL(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+      LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
     }
     if (dbg_env("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
       uint32_t* d_rep;
       HIP_TRY(hipMalloc((void**)&d_rep, n_units * 16));
-      hipLaunchKernelGGL(verify_index_kernel, dim3((uint32_t)((n_units + 63) / 64)), dim3(64), 0, s, ip, d_rep);
+      LAUNCH(verify_index_kernel, dim3((uint32_t)((n_units + 63) / 64)), dim3(64), 0, s, ip, d_rep);
       std::vector<uint32_t> rep(n_units * 4);
       HIP_TRY(hipMemcpyAsync(rep.data(), d_rep, n_units * 16, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
@@ -568,7 +575,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     }
     {
       LaunchTimer lt(c, s, 0);
-      hipLaunchKernelGGL(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
+      LAUNCH(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
                          kOutAlloc + (dbg_env("SNAPPY_HIP_ONE_WG") ? 8192 : 0) /* DEBUG: one per CU */, s, dp);
     }
     if (d_stats) {
@@ -586,12 +593,12 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   if (!v1 && !dbg_env("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined
     LaunchTimer lt(c, s, 5);
     p.only_status = kNeedsOnePass;
-    hipLaunchKernelGGL(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+    LAUNCH(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
     p.only_status = 0;
   }
   if (stream_pass) {
     LaunchTimer lt(c, s, 5);
-    hipLaunchKernelGGL(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+    LAUNCH(decode_units_kernel<true>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
   }
   if (d_crc) {  // units that did not get their CRC from the indexed decode kernel (all of them for v1)
     CrcParams cp{};
@@ -604,7 +611,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     cp.col_mul = c->d_col_mul;
     cp.done = (const uint8_t*)d_done;
     LaunchTimer lt(c, s, 2);
-    hipLaunchKernelGGL(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, cp);
+    LAUNCH(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, cp);
   }
   HIP_TRY(hipGetLastError());
   return SNAPPY_HIP_OK;
@@ -722,8 +729,8 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
     FrameStitch stitch{};
     {
       LaunchTimer lt(c, s, 6);
-      hipLaunchKernelGGL(frame_chase_kernel, dim3(kFrameChasers), dim3(64), 0, s, d_in, n, p0, slice, d_chase, d_lists);
-      hipLaunchKernelGGL(frame_stitch_kernel, dim3(1), dim3(1024), 0, s, d_chase, d_lists, n, p0, slice, d_base, d_first,
+      LAUNCH(frame_chase_kernel, dim3(kFrameChasers), dim3(64), 0, s, d_in, n, p0, slice, d_chase, d_lists);
+      LAUNCH(frame_stitch_kernel, dim3(1), dim3(1024), 0, s, d_chase, d_lists, n, p0, slice, d_base, d_first,
                          d_stitch);
     }
     HIP_TRY(hipGetLastError());
@@ -767,10 +774,10 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       fp.is_stored = d_is_stored;
       fp.irregular = d_flags;
       const uint32_t grid = (uint32_t)((H + 255) / 256);
-      hipLaunchKernelGGL(frame_fill_kernel, dim3(grid), dim3(256), 0, s, fp);
-      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ulen, (uint64_t)H, (uint64_t)0, d_out_at);
-      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_comp, (uint64_t)H, (uint64_t)0, d_comp_at);
-      hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_stored, (uint64_t)H, (uint64_t)0, d_stored_at);
+      LAUNCH(frame_fill_kernel, dim3(grid), dim3(256), 0, s, fp);
+      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ulen, (uint64_t)H, (uint64_t)0, d_out_at);
+      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_comp, (uint64_t)H, (uint64_t)0, d_comp_at);
+      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_stored, (uint64_t)H, (uint64_t)0, d_stored_at);
       FrameScatterParams xp{};
       xp.in = d_in;
       xp.n = n;
@@ -790,7 +797,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       xp.check_header = check_header;
       xp.res = d_res;
       xp.fast_ok = d_flags + 1;
-      hipLaunchKernelGGL(frame_scatter_kernel, dim3(grid), dim3(256), 0, s, xp);
+      LAUNCH(frame_scatter_kernel, dim3(grid), dim3(256), 0, s, xp);
       HIP_TRY(hipGetLastError());
       uint32_t flags[2] = {0, 0};
       HIP_TRY(hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, s));
@@ -820,7 +827,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
     sp.res = d_res;
     {
       LaunchTimer lt(c, s, 6);
-      hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(64), 0, s, sp);
+      LAUNCH(frame_scan_kernel, dim3(1), dim3(64), 0, s, sp);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, s));
@@ -841,7 +848,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       int st = snappy_hip_crc32c_d(c, d_in, stored.in_off, stored.in_len, res.n_stored, stored_crc, s);
       if (st) return st;
     }
-    hipLaunchKernelGGL(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
+    LAUNCH(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
                        stored.out_off, d_res, d_out);
     HIP_TRY(hipGetLastError());
   }
@@ -854,7 +861,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
   vp.stored_crc = stored_crc;
   vp.check_integrity = check_integrity;
   vp.out = d_verdict;
-  hipLaunchKernelGGL(frame_verdict_kernel, dim3(1), dim3(1024), 0, s, vp);
+  LAUNCH(frame_verdict_kernel, dim3(1), dim3(1024), 0, s, vp);
   HIP_TRY(hipGetLastError());
   FrameVerdict v{};
   HIP_TRY(hipMemcpyAsync(&v, d_verdict, sizeof v, hipMemcpyDeviceToHost, s));
@@ -1271,13 +1278,13 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
       sp.locate = 0;
       if (r + 1 == r_hi) HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4, s));  // the look reads the last round's words
       LaunchTimer lt(c, s, 7);
-      hipLaunchKernelGGL(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+      LAUNCH(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
     }
     // is this the right state already?  (split_check_kernel: a proof that does not depend on the rounds)
     HIP_TRY(hipMemsetAsync(reached, 0, (size_t)nseg * 4, s));
     HIP_TRY(hipMemsetAsync(changed + 64, 0, 4, s));
-    hipLaunchKernelGGL(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 0);
-    hipLaunchKernelGGL(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 1);
+    LAUNCH(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 0);
+    LAUNCH(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_changed, changed, sizeof h_changed, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1289,14 +1296,14 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
       fprintf(stderr, "SPLIT round %d changed %u check %s\n", r, h_changed[0], converged ? "ok" : "no");
   }
   if (!converged) return -1;
-  hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
+  LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108 (or an invalid element cut the walk short)
   (void)nblk;
   sp.locate = 1;
-  hipLaunchKernelGGL(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+  LAUNCH(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
   HIP_TRY(hipGetLastError());
   uint32_t h_flags[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
@@ -1361,7 +1368,7 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
     HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
     ip.idx = (uint32_t*)d_sdbg;
   }
-  if (spec < 0) hipLaunchKernelGGL(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
+  if (spec < 0) LAUNCH(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
   if (d_sdbg) {
     unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, d_sdbg, 64, hipMemcpyDeviceToHost, s));

@@ -466,3 +466,70 @@ def test_launch_order_large_batch(hip, orc, torch_mod):
         results.append((out.copy(), crcs.copy()))
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
     ctx.close()
+
+
+def test_units_flush_against_exact_size_allocations(hip, orc):
+    """include/snappy_hip.h: no padding is required -- a unit may start at the first byte and end at
+    the last byte of a hipMalloc of exactly its size (the kernels' 16-byte loads are aligned and stay
+    inside the lines that hold the unit's ends).  Input, slots, packed stream and output are
+    hipMalloc'ed at their exact sizes through the HIP runtime, no torch allocator in between."""
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rt.hipFree.argtypes = [ctypes.c_void_p]
+
+    def dmalloc(n):
+        p = ctypes.c_void_p()
+        assert rt.hipMalloc(ctypes.byref(p), max(n, 1)) == 0
+        return p.value
+
+    def up(data):
+        p = dmalloc(len(data))
+        assert rt.hipMemcpy(p, bytes(data), len(data), 1) == 0
+        return p
+
+    def down(p, n):
+        b = ctypes.create_string_buffer(max(n, 1))
+        assert rt.hipMemcpy(b, p, n, 2) == 0
+        return b.raw[:n]
+
+    ctx = hip.Context(0)
+    src = golden_text = open(os.path.join(os.path.dirname(__file__), "golden", "data", "alice29.txt"), "rb").read()
+    for n in (152089, 65536, 65537, 4099, 17, 1):
+        data = src[:n]
+        nb = (n + 65535) // 65536
+        d_in = up(data)
+        d_slots = dmalloc(nb * hip.SLOT_STRIDE)
+        d_sizes = dmalloc(nb * 4)
+        ctx.encode_blocks(d_in, n, d_slots, d_sizes)
+        ctx.sync()
+        sizes = np.frombuffer(down(d_sizes, nb * 4), dtype=np.uint32)
+        total = int(sizes.sum())
+        d_packed = dmalloc(total)
+        d_offsets = dmalloc((nb + 1) * 8)
+        ctx.pack(d_slots, d_sizes, nb, d_packed, d_offsets)
+        ctx.sync()
+        packed = down(d_packed, total)
+        want = b"".join(orc.encode(data[i:i + 65536]) for i in range(0, n, 65536))
+        assert packed == want, n
+        offs = np.frombuffer(down(d_offsets, (nb + 1) * 8), dtype=np.int64)
+        d_out = dmalloc(n)
+        oo = np.arange(nb, dtype=np.int64) * 65536
+        oc = np.minimum(65536, n - oo).astype(np.uint32)
+        d_oo, d_oc = up(oo.tobytes()), up(oc.tobytes())
+        d_ol, d_st = dmalloc(nb * 4), dmalloc(nb * 4)
+        ctx.decode_blocks(d_packed, d_offsets, d_sizes, nb, d_out, d_oo, d_oc, d_ol, d_st)
+        ctx.sync()
+        assert down(d_out, n) == data, n
+        assert not np.frombuffer(down(d_st, nb * 4), dtype=np.uint32).any()
+        # the framed stream and the raw buffer, resident, exact sizes
+        fr = orc.encode_framed(data)
+        d_fr, d_fo = up(fr), dmalloc(n)
+        assert ctx.uncompress_framed(d_fr, len(fr), d_fo, n) == (0, len(fr), n) and down(d_fo, n) == data
+        raw = orc.encode(data)
+        d_raw, d_ro = up(raw), dmalloc(n)
+        assert ctx.uncompress(d_raw, len(raw), d_ro, n) == (0, n) and down(d_ro, n) == data
+        for p in (d_in, d_slots, d_sizes, d_packed, d_offsets, d_out, d_oo, d_oc, d_ol, d_st, d_fr, d_fo, d_raw, d_ro):
+            rt.hipFree(p)
+    ctx.close()
