@@ -153,6 +153,17 @@ int snappy_hip_compress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint6
 int snappy_hip_uncompress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
                                    uint64_t cap, int check_header, int check_integrity,
                                    uint64_t* read, uint64_t* written, void* stream);
+/* Block-range sharding over n contexts (one per GPU) from ONE process, with the host-side
+ * concatenate: shard k = d_in[k][0 .. in_len[k]) (whole 64 KiB blocks, except the last shard's tail),
+ * resident on ctxs[k]'s GPU, is encoded and packed there; the n shard totals are scanned on the host
+ * (the reference's serial `written += ...`, snappy.nim:56-62, :149-153) and every shard is downloaded
+ * to its offset in the ONE host buffer `out` (page-locked memory lets the downloads run side by
+ * side).  framed != 0: compressFramed of the concatenated input; 0: compress (total < 2^32).
+ * shard_off (may be NULL): the n + 1 scanned offsets.  The result is byte-identical to one call
+ * over the concatenated input. */
+int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
+                               const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
+                               uint64_t* written, uint64_t* shard_off);
 /* Average duration in milliseconds of the last timed kernel launches, measured with HIP
  * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
  * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
     "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d", "snappy_hip_uncompress_d",
+    "snappy_hip_compress_shards",
 ]
 
 
@@ -94,6 +95,10 @@ lib.snappy_hip_uncompress_framed_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, c
                                                ctypes.c_int, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_uint64),
                                                ctypes.POINTER(ctypes.c_uint64), _vp]
+lib.snappy_hip_compress_shards.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ctypes.POINTER(_vp),
+                                           ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _vp,
+                                           ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                           ctypes.POINTER(ctypes.c_uint64)]
 lib.snappy_hip_uncompress_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), _vp]
 lib.snappy_hip_ctx_timing.argtypes = [_vp, ctypes.c_int]
@@ -259,6 +264,25 @@ def _after_torch(stream, *tensors):
             import torch
             torch.cuda.current_stream(t.device).synchronize()
             return
+
+
+def compress_shards(ctxs, d_ins, lens, out_ptr, cap, framed=True):
+    """snappy_hip_compress_shards: shard k (device tensor d_ins[k], lens[k] bytes, on ctxs[k]'s GPU) is
+    encoded there, and all shards land in ONE host buffer (out_ptr: address, ideally page-locked) at
+    their scanned offsets.  Returns (written, offsets[n + 1])."""
+    n = len(ctxs)
+    for c, t in zip(ctxs, d_ins):
+        _after_torch(None, t)
+    hs = (_vp * n)(*[c._h for c in ctxs])
+    ps = (_vp * n)(*[_ptr(t) for t in d_ins])
+    ls = (ctypes.c_uint64 * n)(*[int(x) for x in lens])
+    offs = (ctypes.c_uint64 * (n + 1))()
+    w = ctypes.c_uint64()
+    st = _check_device(lib.snappy_hip_compress_shards(hs, n, ps, ls, int(framed), out_ptr, cap,
+                                                      ctypes.byref(w), offs))
+    if st != OK:
+        raise ValueError("compress_shards: status %d" % st)
+    return w.value, list(offs)
 
 
 class Context:

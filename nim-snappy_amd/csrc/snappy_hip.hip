@@ -872,6 +872,110 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
   return SNAPPY_HIP_OK;
 }
 
+// Block-range sharding over several contexts (one per GPU) from ONE process, with the host-side
+// concatenate of BASELINE's north star: shard k (a contiguous range of 64 KiB blocks, resident on
+// context k's GPU) is encoded and packed there; the only exchange is the n shard totals, whose
+// exclusive scan -- the reference's serial `written += ...`, snappy.nim:56-62, :149-153 -- gives every
+// shard its place in the ONE host buffer, and all shards then download side by side, each over its
+// own GPU's link.  framed != 0: compressFramed (stream identifier + one chunk per block, any total
+// length); framed == 0: compress (one varint, total < 2^32).  out should be page-locked for the
+// downloads to overlap.  shard_off (may be NULL) receives the n + 1 scanned offsets.
+extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
+                                          const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
+                                          uint64_t* written, uint64_t* shard_off) {
+  *written = 0;
+  if (n <= 0) return SNAPPY_HIP_INVALID_INPUT;
+  uint64_t total_in = 0;
+  for (int k = 0; k < n; k++) {
+    if (k + 1 < n && in_len[k] % kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // shards are whole blocks
+    total_in += in_len[k];
+  }
+  if (!framed && total_in > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:41-42
+  const uint64_t need = framed ? snappy_hip_max_compressed_len_framed((int64_t)total_in)
+                               : 32 + total_in + total_in / 6;
+  if (cap < need) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:44-45, :139-140
+  uint64_t base = 0;
+  if (framed) {
+    memcpy(out, kFramingHeader, sizeof kFramingHeader);
+    base = sizeof kFramingHeader;
+  } else {
+    base = (uint64_t)varint_encode_u32((uint32_t)total_in, out);
+  }
+  std::vector<uint64_t> totals(n, 0);
+  std::vector<void*> packed(n, nullptr);
+  std::vector<int> status(n, SNAPPY_HIP_OK);
+  std::vector<std::string> errs(n);
+  const int unit = framed ? kUnitFrame : kUnitBody;
+  auto phase1 = [&](int k) {  // encode + pack on GPU k, report the shard's size
+    snappy_hip_ctx* c = ctxs[k];
+    DeviceGuard guard(c->device);
+    const uint64_t nb = (in_len[k] + kMaxBlockLen - 1) / kMaxBlockLen;
+    if (nb == 0) return;
+    void *d_slots, *d_sizes, *d_out;
+    int st;
+    if ((st = ws_get(c, 17, nb * (size_t)kSlotStride, &d_slots)) || (st = ws_get(c, 18, nb * 4 + (nb + 1) * 8 + 64, &d_sizes)) ||
+        (st = ws_get(c, 4, nb * (size_t)(kMaxCompressedBlockLen + 16) + 64, &d_out))) {
+      status[k] = st;
+      errs[k] = g_last_error;
+      return;
+    }
+    void* d_offsets = (uint8_t*)d_sizes + ((nb * 4 + 15) & ~(size_t)15);
+    if ((st = snappy_hip_encode_blocks_d(c, d_in[k], in_len[k], kMaxBlockLen, unit, (uint8_t*)d_slots, kSlotStride,
+                                         (uint32_t*)d_sizes, nullptr)) ||
+        (st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, nb, 0, (uint8_t*)d_out,
+                                (uint64_t*)d_offsets, nullptr))) {
+      status[k] = st;
+      errs[k] = g_last_error;
+      return;
+    }
+    uint64_t end = 0;
+    if (hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+      status[k] = SNAPPY_HIP_DEVICE_ERROR;
+      return;
+    }
+    totals[k] = end;
+    packed[k] = d_out;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; k++) th.emplace_back(phase1, k);
+    phase1(0);
+    for (auto& t : th) t.join();
+  }
+  for (int k = 0; k < n; k++)
+    if (status[k]) {
+      g_last_error = errs[k];
+      return status[k];
+    }
+  std::vector<uint64_t> off(n + 1, base);  // the exchange: n totals -> exclusive scan
+  for (int k = 0; k < n; k++) off[k + 1] = off[k] + totals[k];
+  if (off[n] > cap) {
+    g_last_error = "internal: packed stream exceeds the caller's bound";
+    return SNAPPY_HIP_DEVICE_ERROR;
+  }
+  auto phase2 = [&](int k) {  // every shard lands at its scanned offset
+    snappy_hip_ctx* c = ctxs[k];
+    if (!totals[k]) return;
+    DeviceGuard guard(c->device);
+    if (hipMemcpyAsync(out + off[k], packed[k], totals[k], hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+      status[k] = SNAPPY_HIP_DEVICE_ERROR;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n; k++) th.emplace_back(phase2, k);
+    phase2(0);
+    for (auto& t : th) t.join();
+  }
+  for (int k = 0; k < n; k++)
+    if (status[k]) return status[k];
+  if (shard_off)
+    for (int k = 0; k <= n; k++) shard_off[k] = off[k];
+  *written = off[n];
+  return SNAPPY_HIP_OK;
+}
+
 // =============================================================================================
 // host-side scalar helpers
 // =============================================================================================

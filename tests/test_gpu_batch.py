@@ -533,3 +533,36 @@ def test_units_flush_against_exact_size_allocations(hip, orc):
         for p in (d_in, d_slots, d_sizes, d_packed, d_offsets, d_out, d_oo, d_oc, d_ol, d_st, d_fr, d_fo, d_raw, d_ro):
             rt.hipFree(p)
     ctx.close()
+
+
+def test_shards_from_one_process_land_in_one_host_buffer(hip, orc, torch_mod):
+    """BASELINE configs[4], single-process form (snappy_hip_compress_shards): two contexts, block ranges
+    encoded separately, the shard totals scanned on the host, every shard downloaded to its offset in
+    ONE page-locked buffer -- byte-identical to the oracle's encoding of the whole input, framed and
+    raw, with a ragged tail in the last shard"""
+    torch = torch_mod
+    import json
+    import subprocess
+    import sys
+    import corpus
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nb = 96
+    with open(os.path.join(ROOT, "tests", "golden", "data", "alice29.txt"), "rb") as fh:
+        tail = fh.read()[:12345]
+    src = corpus.make_blocks(0, nb).tobytes() + tail
+    ctxs = [hip.Context(0), hip.Context(0)]
+    cut = 64 * 65536
+    d_ins = [_dev(torch, np.frombuffer(src[:cut], dtype=np.uint8)), _dev(torch, np.frombuffer(src[cut:], dtype=np.uint8))]
+    lens = [cut, len(src) - cut]
+    for framed, want in ((True, orc.encode_framed(src)), (False, orc.encode(src))):
+        cap = hip.max_compressed_len_framed(len(src)) if framed else hip.max_compressed_len(len(src))
+        out = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        written, offs = hip.compress_shards(ctxs, d_ins, lens, out.data_ptr(), cap, framed=framed)
+        assert out[:written].numpy().tobytes() == want
+        assert offs[0] in (10, 4) and offs[-1] == written and offs[0] < offs[1] < offs[2]
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shards_one_process.py"), "--gpus", "2", "--same-gpu",
+                         "--total-gib", "0.25", "--check", "--reps", "1"], capture_output=True, text=True, timeout=600)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    assert json.loads(rc.stdout.strip().splitlines()[-1])["equals_oracle"] is True
+    for c in ctxs:
+        c.close()

@@ -13,6 +13,14 @@ def block_range(rank, world, blocks_per_rank):
     return lo, lo + blocks_per_rank
 
 
+def split_range(k, n, total_blocks):
+    """Strong scaling: shard k of n of a FIXED number of blocks (contiguous, sizes differ by at most one)."""
+    assert 0 <= k < n
+    base, extra = divmod(total_blocks, n)
+    lo = k * base + min(k, extra)
+    return lo, lo + base + (1 if k < extra else 0)
+
+
 def max_over_ranks(dist, value, device=None):
     """MAX of a python float over all ranks (identity when dist is None)."""
     if dist is None:
