@@ -1,0 +1,46 @@
+"""tools/encode_model.py -- the round structure of the HIP encoder (64 consecutive positions per round,
+copies chained inside the round, the table left as the sequential loop leaves it) replayed lane by lane
+on the CPU -- must give the oracle's bytes: the exactness argument of csrc/encode_kernel.h, checked
+without a GPU."""
+import ctypes
+
+import pytest
+
+import cases
+from conftest import golden_file
+
+
+def _oracle_block(orc, b):
+    buf = ctypes.create_string_buffer(80000)
+    k = orc.lib.sor_encode_block(bytes(b), len(b), buf)
+    return buf.raw[:k]
+
+
+@pytest.mark.parametrize("name,off,n", [("alice29.txt", 0, 30000), ("html", 1000, 20000), ("urls.10K", 5000, 16000),
+                                        ("kppkn.gtb", 0, 12000), ("fireworks.jpeg", 0, 20000),
+                                        ("geo.protodata", 300, 9000)])
+def test_model_equals_oracle_on_data(orc, name, off, n):
+    import encode_model as em
+    blk = golden_file(name)[off:off + n]
+    st = {}
+    assert em.encode_block(blk, st) == _oracle_block(orc, blk)
+    assert st["dense_rounds"] >= 1
+
+
+def test_model_equals_oracle_on_patterns_and_edges(orc):
+    import random
+    import encode_model as em
+    rnd = random.Random(7)
+    text = golden_file("alice29.txt")
+    for n in list(range(1, 90)) + [255, 256, 257, 1023, 1024, 1025, 4096]:
+        for src in (text, bytes(5000), cases.mod10(5000), cases.ramp(5000)):
+            assert em.encode_block(src[:n]) == _oracle_block(orc, src[:n]), n
+    for i in range(1, 33):  # tests/test_snappy.nim:110-116
+        b = b"aaaa" + b"b" * i + b"aaaabbbb" * 3 + b"x" * 20
+        assert em.encode_block(b) == _oracle_block(orc, b)
+    for _ in range(12):  # few symbols: many lanes of a round share a table slot
+        a = rnd.randrange(2, 6)
+        b = bytes(rnd.randrange(a) + 65 for _ in range(rnd.randrange(100, 3000)))
+        assert em.encode_block(b) == _oracle_block(orc, b)
+    s = bytes(rnd.randrange(256) for _ in range(700))
+    assert em.encode_block((s * 9)[:6000]) == _oracle_block(orc, (s * 9)[:6000])

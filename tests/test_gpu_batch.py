@@ -217,14 +217,15 @@ def test_full_size_round_trip_properties(hip, torch_mod):
     monotone and consistent with the sizes, framed CRC-of-output equals CRC-of-input."""
     import corpus
     torch = torch_mod
-    nb = int(os.environ.get("SNAPPY_HIP_TEST_BLOCKS", "16384"))
+    nb = int(os.environ.get("SNAPPY_HIP_TEST_BLOCKS", "65536"))
     ctx = hip.Context(0)
     d_in = torch.empty(nb * 65536, dtype=torch.uint8, device="cuda")
     step = 2048
     for b0 in range(0, nb, step):
         c = min(step, nb - b0)
-        d_in[b0 * 65536:(b0 + c) * 65536] = torch.from_numpy(
-            corpus.make_blocks(b0, c).reshape(-1)).cuda()
+        d_in[b0 * 65536:(b0 + c) * 65536] = corpus.make_blocks_torch(torch, b0, c, "cuda").reshape(-1)
+    chk = corpus.make_blocks(nb - 8, 8).reshape(-1)  # (the device generator gives the numpy generator's bytes)
+    assert np.array_equal(d_in[(nb - 8) * 65536:].cpu().numpy(), chk)
     d_slots, d_sizes, d_offsets, d_out, total = _encode_pack(hip, torch, ctx, d_in, nb * 65536,
                                                              hip.UNIT_RAW)
     offs = d_offsets.cpu().numpy()
