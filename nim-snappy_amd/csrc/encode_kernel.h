@@ -57,10 +57,21 @@ __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
   return ((u * 0x1e35a7bdu) >> (32 - kMaxTableBits)) & mask;  // encoder.nim:36-37
 }
 
+#ifdef ENC_BLOCK_IN_LDS
+extern __shared__ __attribute__((aligned(16))) uint8_t s_enc_dyn[];
+#endif
 __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
   __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
+#ifdef ENC_BLOCK_IN_LDS
+  // EXPERIMENT (north_star's layout, profiles/README.md): the whole block staged in LDS -- the window
+  // is the block, candidates come from it; 105 KiB per block, so ONE block per CU instead of four
+  uint8_t* const s_win = s_enc_dyn;
+  constexpr uint32_t kWin = kMaxBlockLen + 32;
+#else
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
+  constexpr uint32_t kWin = kWinSize;
+#endif
   __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
   __shared__ uint16_t s_seq_step[kSeqLen];
 
@@ -103,11 +114,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   auto fill_window = [&](uint32_t p_first) {
     wq = (p_first + shift) & ~15u;
     wave_fence();
-    for (uint32_t i = lane; i < kWinSize / 16; i += 64) {
+    for (uint32_t i = lane; i < kWin / 16; i += 64) {
       const uint32_t q = wq + 16 * i;
       if (q < q_end) *reinterpret_cast<uint4*>(s_win + 16 * i) = *reinterpret_cast<const uint4*>(g0 + q);
     }
-    wend = wq + kWinSize < q_end ? wq + kWinSize : q_end;
+    wend = wq + kWin < q_end ? wq + kWin : q_end;
     wave_fence();
   };
   auto in_window = [&](uint32_t p, uint32_t bytes) -> bool {
@@ -455,7 +466,20 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           }
           losers &= ~g;
         }
-#ifndef ENC_EARLY_FETCH
+#if defined(ENC_BLOCK_IN_LDS)
+        cv = make_uint4(0, 0, 0, 0);
+        {
+          const uint32_t qa = valid ? (cand + shift - wq) : 0;
+          const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+          const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
+          const uint32_t sh8 = (qa & 3) * 8;
+          cv.x = __funnelshift_r(r0, r1, sh8);
+          cv.y = __funnelshift_r(r1, r2, sh8);
+          cv.z = __funnelshift_r(r2, r3, sh8);
+          cv.w = __funnelshift_r(r3, r4, sh8);
+        }
+        if (0) {
+#elif !defined(ENC_EARLY_FETCH)
         __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
         if (0) {
 #else

@@ -427,8 +427,14 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   }
   {
     LaunchTimer lt(c, s, 1);
+#ifdef ENC_BLOCK_IN_LDS
+    HIP_TRY(hipFuncSetAttribute((const void*)encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kMaxBlockLen + 64));
+    LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64), kMaxBlockLen + 64, s, p);
+#else
     LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
-                       dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
+           dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
+#endif
   }
   if (d_estats) {
     unsigned long long h[16];
