@@ -1339,7 +1339,7 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // -1: not applicable (no fixed point within the round limit, an element straddles a block boundary).
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s) {
-  constexpr int kMaxRounds = 40;
+  constexpr int kMaxRounds = 64;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
   void* base;
   int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
@@ -1375,12 +1375,16 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;
-  const uint32_t grid = (nseg + 255) / 256;
+  const uint32_t grid = (nseg + 255) / 256;            // (the check kernels)
+  const uint32_t wgrid = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 64 KiB of staged stream each)
+  HIP_TRY(hipFuncSetAttribute((const void*)split_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   uint32_t h_changed[128];
   int r = 0;
   bool converged = false;
   while (r < kMaxRounds && !converged) {
-    const int r_hi = r + (r == 0 ? 3 : 4) < kMaxRounds ? r + (r == 0 ? 3 : 4) : kMaxRounds;  // a few rounds per look
+    // (a look costs about two rounds: few at first, where text-like streams settle, then further apart)
+    const int step = r < 8 ? 4 : (r < 16 ? 6 : 10);
+    const int r_hi = r + step < kMaxRounds ? r + step : kMaxRounds;
     for (; r < r_hi; r++) {
       sp.nxt_in = nxt[r & 1];
       sp.nxt_out = nxt[(r + 1) & 1];
@@ -1388,7 +1392,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
       sp.locate = 0;
       if (r + 1 == r_hi) HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4, s));  // the look reads the last round's words
       LaunchTimer lt(c, s, 7);
-      LAUNCH(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+      LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
     }
     // is this the right state already?  (split_check_kernel: a proof that does not depend on the rounds)
     HIP_TRY(hipMemsetAsync(reached, 0, (size_t)nseg * 4, s));
@@ -1401,7 +1405,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     converged = h_changed[64] == 0;
     // (streams of long literals back to back -- incompressible data -- settle one literal per round:
     // past a point the serial walk is the better deal)
-    if (!converged && r >= 15 && h_changed[0] > nseg / 32) r = kMaxRounds;
+    if (!converged && r >= 31 && h_changed[0] > nseg / 64) r = kMaxRounds;
     if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
       fprintf(stderr, "SPLIT round %d changed %u check %s\n", r, h_changed[0], converged ? "ok" : "no");
   }
@@ -1413,7 +1417,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108 (or an invalid element cut the walk short)
   (void)nblk;
   sp.locate = 1;
-  LAUNCH(split_walk_kernel, dim3(grid), dim3(256), 0, s, sp);
+  LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
   HIP_TRY(hipGetLastError());
   uint32_t h_flags[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));

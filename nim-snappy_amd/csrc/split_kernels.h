@@ -22,7 +22,7 @@
 
 namespace snappy_hip {
 
-constexpr uint32_t kSplitSeg = 1024;     // stream bytes per lane
+constexpr uint32_t kSplitSeg = 256;      // stream bytes per lane
 // Segments one element may claim: a literal of a whole 64 KiB block and its length bytes.  (A walk
 // that starts wrong reads payload bytes as tags, and one byte in fifty is the tag of a literal with
 // explicit length: unbounded, such claims would keep overriding the right ones far downstream.
@@ -47,30 +47,37 @@ struct SplitParams {
   int locate;
 };
 
-// the element at p: false = invalid (decoder.nim:54-57, :67-68, :77-79, truncated copies)
-__device__ __forceinline__ bool split_element(const uint8_t* in, uint32_t n, uint32_t p, uint32_t* L, uint32_t* size) {
-  uint32_t tag, b14;
-  if (p + 8 <= n) {
-    const uint32_t w0 = ld32u(in + p), w1 = ld32u(in + p + 4);
-    tag = w0 & 0xff;
-    b14 = (w0 >> 8) | (w1 << 24);
-  } else {
-    uint32_t b[5] = {0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < 5 && p + i < n; i++) b[i] = in[p + i];
-    tag = b[0];
-    b14 = b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24);
-  }
-  return decode_element_bf(tag, b14, n - p - 1, L, size);
+// One wave per workgroup: its 64 segments are 64 KiB of stream, staged in LDS with coalesced loads
+// before the lanes walk them (64 lanes reading their own KiB byte by byte straight from memory move a
+// cache line per element and lane: 1.4 GB of L2 traffic for a round over 32 MiB of stream).
+constexpr uint32_t kSplitWg = 64;
+constexpr uint32_t kSplitStage = kSplitWg * kSplitSeg + 16;  // + the bytes an element's header may reach over
+extern __shared__ __attribute__((aligned(16))) uint8_t s_split_dyn[];
+
+// the element at p (stage: the workgroup's range of the stream, from stream position lo): false = invalid
+// (decoder.nim:54-57, :67-68, :77-79, truncated copies)
+__device__ __forceinline__ bool split_element(const uint8_t* stage, uint32_t lo, uint32_t n, uint32_t p, uint32_t* L,
+                                              uint32_t* size, uint32_t* tag_out) {
+  const uint8_t* q = stage + (p - lo);
+  uint32_t b[5];
+#pragma unroll
+  for (uint32_t i = 0; i < 5; i++) b[i] = q[i];  // (staged bytes behind the stream's end are zero)
+  *tag_out = b[0];
+  return decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), n - p - 1, L, size);
 }
 
-__global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
-  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= p.nseg) return;
+__global__ __launch_bounds__(kSplitWg) void split_walk_kernel(SplitParams p) {
+  const uint32_t s = blockIdx.x * kSplitWg + threadIdx.x;
+  const uint32_t wg_lo = blockIdx.x * kSplitWg * kSplitSeg;
+  uint8_t* const stage = s_split_dyn;
+  const bool live = s < p.nseg;  // (lanes behind the last segment only help with the staging)
   const uint32_t seg_lo = s * kSplitSeg;
   const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
   uint32_t e = seg_lo;  // the guess
   bool claimed = s == 0;
-  if (p.locate) {
+  if (!live) {
+    e = 0xffffffffu;
+  } else if (p.locate) {
     e = p.prev[s] & 0x7fffffffu;  // (the entries of the last round)
   } else if (s == 0) {
     e = 0;
@@ -81,14 +88,14 @@ __global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
       claimed = true;
     }
   }
-  bool same = false;
-  if (!p.locate) {
+  bool same = !live;
+  if (!p.locate && live) {
     // (bit 31: the entry was claimed -- a walk from a claimed entry starts trusted, so a guess that
     // turns into a claim of the same position is a different walk)
     const uint32_t pw = e | (claimed ? 0x80000000u : 0u);
     same = pw == p.prev[s];
     const uint64_t ch = __ballot(!same);  // (one atomic per wave, not per lane)
-    if (ch && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(ch)) atomicAdd(p.changed, (uint32_t)__builtin_popcountll(ch));
+    if (ch && threadIdx.x == (uint32_t)__builtin_ctzll(ch)) atomicAdd(p.changed, (uint32_t)__builtin_popcountll(ch));
     p.prev[s] = pw;
     const_cast<unsigned long long*>(p.nxt_in)[s] = ~0ull;  // (mine to reset: this buffer is written again next round)
   }
@@ -98,8 +105,25 @@ __global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
   // "native" elements in a row behind it: its far claims would otherwise keep overriding right ones
   // downstream.  A walk from a claimed entry starts trusted, one from a guess does not.
   uint32_t pos = e, out = 0, clean = claimed ? kSplitClean : 0;
-  uint64_t op = p.locate ? p.out_at[s] : 0;
+  uint64_t op = (p.locate && live) ? p.out_at[s] : 0;
   bool bad = false;
+  if (__ballot(!same && e < seg_hi)) {  // somebody walks: stage the workgroup's 64 KiB (+16) of stream
+    for (uint32_t i = threadIdx.x * 16; i < kSplitStage; i += kSplitWg * 16) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const uint64_t g = (uint64_t)wg_lo + i;
+      if (g + 16 <= p.n) {
+        __builtin_memcpy(&v, p.in + g, 16);
+      } else {
+        uint8_t t[16] = {0};
+        for (uint32_t k = 0; k < 16 && g + k < p.n; k++) t[k] = p.in[g + k];
+        __builtin_memcpy(&v, t, 16);
+      }
+      *reinterpret_cast<uint4*>(stage + i) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!live) return;
   if (same) {  // same entry as last round: same walk, same result
     const uint32_t m = p.memo[s];
     pos = m & 0x7fffffffu;
@@ -107,8 +131,8 @@ __global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
     bad = pos == 0x7fffffffu;
   } else {
     while (pos < seg_hi) {
-      uint32_t L, size;
-      if (!split_element(p.in, p.n, pos, &L, &size)) {
+      uint32_t L, size, tg;
+      if (!split_element(stage, wg_lo, p.n, pos, &L, &size, &tg)) {
         bad = true;
         break;
       }
@@ -117,7 +141,6 @@ __global__ __launch_bounds__(256) void split_walk_kernel(SplitParams p) {
         else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
         op += L;
       }
-      const uint32_t tg = p.in[pos];
       clean = ((tg & 3) == 3 || ((tg & 3) == 0 && (tg >> 2) >= 62)) ? 0 : clean + 1;
       out += L;
       pos += size;
