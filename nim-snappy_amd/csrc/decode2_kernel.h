@@ -737,9 +737,6 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
             if (lane == 0) atomicOr(&s_err, 4u);
             break;
           }
-#ifdef D2_POLL_SLEEP
-          __builtin_amdgcn_s_sleep(D2_POLL_SLEEP);
-#endif
           front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           cbar();
         }

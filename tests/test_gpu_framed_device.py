@@ -166,3 +166,56 @@ def test_tiny_chunks_overflow_the_first_list(dev, orc):
     stream = H + one * n
     st, rd, wr, out = dev.uncompress_framed(stream, n)
     assert (st, rd, wr) == (bh.OK, len(stream), n) and out == b"x" * n
+
+
+def test_random_framed_streams_match_oracle(dev, orc):
+    """streams assembled chunk by chunk from every chunk class (compressed, stored, skippable, padding,
+    repeated identifiers, unknown), random truncations, random corruptions and random output
+    capacities: status and, when ok, both counters and the bytes equal the oracle's -- through the
+    parallel chunk walk where it applies (>= 4 MiB) and the serial one elsewhere"""
+    import random
+    rng = random.Random(77)
+    H = cases.FRAMING_HEADER
+    text = golden_file("alice29.txt") + golden_file("html")
+
+    def chunk(kind, payload=b""):
+        if kind == 0:
+            comp = orc.encode(payload)
+            return b"\x00" + bh.le24(len(comp) + 4) + orc.masked_crc(payload).to_bytes(4, "little") + comp
+        if kind == 1:
+            return b"\x01" + bh.le24(len(payload) + 4) + orc.masked_crc(payload).to_bytes(4, "little") + payload
+        return bytes([kind]) + bh.le24(len(payload)) + payload
+
+    for it in range(28):
+        big = it % 4 == 0  # a stream long enough for the parallel walk
+        parts, plain = [H], bytearray()
+        for _ in range(rng.randint(120, 200) if big else rng.randint(1, 40)):
+            r = rng.random()
+            n = rng.choice([0, 1, 17, 500, 20000, 65536]) if rng.random() < 0.3 else rng.randint(1, 65536)
+            o = rng.randrange(len(text) - 65536)
+            data = text[o:o + n] if rng.random() < 0.7 else rng.randbytes(n)
+            if r < 0.55:
+                parts.append(chunk(0, data)); plain += data
+            elif r < 0.85:
+                parts.append(chunk(1, data)); plain += data
+            elif r < 0.93:
+                parts.append(chunk(rng.randint(0x80, 0xfe), rng.randbytes(rng.randint(0, 300))))
+            elif r < 0.97:
+                parts.append(H)
+            elif not big:
+                parts.append(chunk(rng.randint(2, 0x7f), rng.randbytes(rng.randint(0, 40))))
+        stream = b"".join(parts)
+        variants = [(stream, len(plain))]
+        if len(stream) > 30:
+            cut = rng.randrange(10, len(stream))
+            variants.append((stream[:cut], len(plain)))
+            bad = bytearray(stream)
+            bad[rng.randrange(10, len(stream))] ^= 1 << rng.randrange(8)
+            variants.append((bytes(bad), len(plain)))
+            variants.append((stream, rng.randrange(0, len(plain) + 1)))
+        for data, cap in variants:
+            got = dev.uncompress_framed(data, cap)
+            exp = orc.uncompress_framed(data, cap)
+            assert got[0] == exp[0], (it, got[:3], exp[:3])
+            if exp[0] == bh.OK:
+                assert got[:3] == tuple(exp[:3]) and got[3] == bytes(exp[3]), it

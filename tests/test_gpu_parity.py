@@ -352,3 +352,28 @@ def test_host_calls_from_several_threads(hip, orc):
     assert hip.encode_framed(big) == orc.encode_framed(big)
     assert hip.decode_framed(hip.encode_framed(big)) == big
     assert hip.encode(big) == orc.encode(big)
+
+
+def test_random_multi_block_raw_buffers(hip, orc):
+    """raw buffers of several blocks through the speculative split (csrc/split_kernels.h) and its
+    fallbacks: buffers of the block encoder (text, mixed with incompressible and repetitive blocks),
+    the same with one byte flipped or the tail cut (verdict equality), and foreign streams whose
+    elements ignore the block boundaries -- always the oracle's bytes or the oracle's failure"""
+    rng = random.Random(99)
+    text = golden_file("alice29.txt") + golden_file("html") + golden_file("urls.10K")
+    srcs = [text[:300000], text[:131072] + rng.randbytes(70000) + text[:200000] + bytes(90000),
+            rng.randbytes(200000), (text[1000:9000] * 40)[:400000],
+            b"".join(rng.randbytes(rng.randint(1000, 9000)) * rng.randint(2, 4) for _ in range(30))]
+    for i, src in enumerate(srcs):
+        comp = orc.encode(src)
+        assert hip.decode(comp) == src, i
+        for _ in range(4):
+            bad = bytearray(comp)
+            bad[rng.randrange(5, len(bad))] ^= 1 << rng.randrange(8)
+            assert hip.decode(bytes(bad)) == orc.decode(bytes(bad)), i
+        cut = comp[:rng.randrange(len(comp) // 2, len(comp))]
+        assert hip.decode(cut) == orc.decode(cut) == b"", i
+    for i in range(5):
+        body, plain = _random_stream(rng, rng.choice([200000, 500000]), far=True)
+        raw = _varint(len(plain)) + body
+        assert hip.decode(raw) == orc.decode(raw) == plain, i
