@@ -40,7 +40,10 @@
 
 namespace snappy_hip {
 
-constexpr uint32_t kD2Threads = 512;  // waves 0,1: front end; waves 2-7: resolvers
+#ifndef D2_THREADS
+#define D2_THREADS 512
+#endif
+constexpr uint32_t kD2Threads = D2_THREADS;  // waves 0,1: front end; waves 2..: resolvers
 constexpr uint32_t kD2Pool = kD2Threads / 64 - 2;
 constexpr uint32_t kD2Ring = 4096;
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)

@@ -582,7 +582,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     {
       LaunchTimer lt(c, s, 0);
       LAUNCH(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
-                         kOutAlloc + (dbg_env("SNAPPY_HIP_ONE_WG") ? 8192 : 0) /* DEBUG: one per CU */, s, dp);
+                         kOutAlloc + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
     }
     if (d_stats) {
       unsigned long long h[16];
