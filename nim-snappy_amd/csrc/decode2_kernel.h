@@ -48,8 +48,11 @@ constexpr uint32_t kD2Pool = kD2Threads / 64 - 2;
 constexpr uint32_t kD2Ring = 4096;
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
 constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
-constexpr uint32_t kOutSink = kMaxBlockLen;         // 64 scratch dwords behind the output window,
-constexpr uint32_t kOutAlloc = kMaxBlockLen + 256;  // one per lane (no bank conflicts)
+#ifndef D2_WINDOW
+#define D2_WINDOW 65536  // (experiments only: smaller windows for units of smaller blocks, profiles/README.md)
+#endif
+constexpr uint32_t kOutSink = D2_WINDOW;         // 64 scratch dwords behind the output window,
+constexpr uint32_t kOutAlloc = D2_WINDOW + 256;  // one per lane (no bank conflicts)
 constexpr uint32_t kMaxSteps = kMaxFastIn / kChunk + 2;
 
 struct Decode2Params {
@@ -139,7 +142,11 @@ __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, ui
 // workgroup of a CU (measured: one workgroup per CU with 5 waves per workgroup).
 extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 
+#ifdef D2_MINWAVES  // (experiments: cap the registers so that more workgroups fit a CU)
+__global__ __launch_bounds__(kD2Threads, D2_MINWAVES) void decode_indexed_kernel(Decode2Params prm) {
+#else
 __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Params prm) {
+#endif
   uint8_t* const s_out = s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave
@@ -173,6 +180,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint64_t idx_base = prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride;
   if (st0 != kOk) return;  // the index pass already decided this unit
   if (total == 0) return;
+  if (D2_WINDOW < kMaxBlockLen && total > D2_WINDOW) {
+    if (tid == 0) prm.status[u] = kNeedsOnePass;
+    return;
+  }
 
   // ... then, knowing only where the unit lies: its first bytes (the varint of a raw unit, the first
   // tag), the first index entries and the first 4 KiB of the stream.  The ring is laid out from the
