@@ -428,6 +428,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dec_ms, dec_launches = ctx.kernel_ms(0)   # decode_indexed_kernel (dominant)
     idx_ms, _ = ctx.kernel_ms(4)               # index_units_kernel
+    dec2_ms, _ = ctx.kernel_ms(8)              # the whole-block instantiation over the units the ring one passed on
     ctx.timing(False)
     elapsed = shard.max_over_ranks(dist if world > 1 else None, elapsed, dev)
     # the side numbers are whole-job rates too: all ranks' bytes over the slowest rank's time
@@ -488,6 +489,7 @@ def main():
                 "kernel": "decode_indexed_kernel",
                 "kernel_ms": round(dec_ms, 4),
                 "index_pass_kernel_ms": round(idx_ms, 4),
+                "passed_on_units_kernel_ms": round(dec2_ms, 4),
                 "launches": dec_launches,
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },

@@ -22,6 +22,8 @@ constexpr uint32_t kNeedsStreamKernel = 0x80000000u;
 // Internal: the indexed decoder declined the unit (a limit of its fast path), run the one-pass
 // block kernel on it.
 constexpr uint32_t kNeedsOnePass = 0x80000001u;
+// Internal: the indexed decoder's ring-window instantiation passes the unit on to the whole-block one.
+constexpr uint32_t kNeedsWindow = 0x80000002u;
 
 enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
 

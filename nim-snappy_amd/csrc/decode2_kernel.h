@@ -48,11 +48,14 @@ constexpr uint32_t kD2Pool = kD2Threads / 64 - 2;
 constexpr uint32_t kD2Ring = 4096;
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
 constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
-#ifndef D2_WINDOW
-#define D2_WINDOW 65536  // (experiments only: smaller windows for units of smaller blocks, profiles/README.md)
+// The output window: the whole block (kMaxBlockLen), or a RING of the last kRingWin bytes (see the kernel).
+constexpr uint32_t kRingWin = 32768;
+#ifndef D2_RING
+#define D2_RING 1  // (0: experiments, the whole-block instantiation only)
 #endif
-constexpr uint32_t kOutSink = D2_WINDOW;         // 64 scratch dwords behind the output window,
-constexpr uint32_t kOutAlloc = D2_WINDOW + 256;  // one per lane (no bank conflicts)
+constexpr bool kD2RingFirst = D2_RING != 0;
+// dynamic LDS of a launch: the window and 64 scratch dwords behind it, one per lane (no bank conflicts)
+constexpr uint32_t out_alloc(uint32_t win) { return win + 256; }
 constexpr uint32_t kMaxSteps = kMaxFastIn / kChunk + 2;
 
 struct Decode2Params {
@@ -68,6 +71,7 @@ struct Decode2Params {
   const uint32_t* idx;
   uint64_t n_units;
   int unit;
+  int second;  // the launch after the ring-window one: only the units that one passed on (kNeedsWindow)
   int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
   unsigned long long* stats;  // DEBUG counters (nullptr = off)
   // masked CRC32C of every unit's output, computed from the LDS window while it is flushed
@@ -136,17 +140,26 @@ __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, ui
   }
 }
 
-// The 64 KiB output window is DYNAMIC shared memory (launch with kOutAlloc bytes): with the whole
+// The output window is DYNAMIC shared memory (launch with out_alloc(WIN) bytes): with the whole
 // footprint declared statically the compiler derives "at most N waves per SIMD" from it and pads
 // the kernel's VGPR allocation to enforce that -- which can leave no room for the second
 // workgroup of a CU (measured: one workgroup per CU with 5 waves per workgroup).
 extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 
-#ifdef D2_MINWAVES  // (experiments: cap the registers so that more workgroups fit a CU)
-__global__ __launch_bounds__(kD2Threads, D2_MINWAVES) void decode_indexed_kernel(Decode2Params prm) {
-#else
-__global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Params prm) {
-#endif
+// WIN = kMaxBlockLen: the window holds the whole unit, two workgroups per CU.
+// WIN = kRingWin: the window is a ring of the unit's last WIN output bytes -- out[x] lives at x & (WIN - 1)
+// -- so that THREE workgroups fit a CU (the kernel is bound by a block's chain of steps, and a CU hides
+// one block's chain behind the others': profiles/README.md).  Every step starts by writing the bytes that
+// became final one step ago to HBM; a copy whose source is older than what this step leaves of the ring
+// (ring_lo) reads it back from there -- those bytes were written at least a step earlier (far_lo, with a
+// wait for the stores in front of the barrier in between).  The ring is sound while the output of the step being parsed, the step
+// being resolved and the one before it fit in WIN bytes (checked per step); a unit where they do not is
+// handed to the whole-block instantiation (kNeedsWindow), launched second over the same units.
+template <uint32_t WIN>
+__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode_indexed_kernel(Decode2Params prm) {
+  constexpr bool RING = WIN < kMaxBlockLen;
+  constexpr uint32_t kOutSink = WIN;
+  auto wa = [](uint32_t x) -> uint32_t { return RING ? (x & (WIN - 1)) : x; };  // window address of output byte x
   uint8_t* const s_out = s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave
@@ -178,12 +191,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
   const uint32_t n_all = prm.in_len[u];
   const uint64_t out_off = prm.out_off[u];
   const uint64_t idx_base = prm.idx_off ? prm.idx_off[u] : u * prm.idx_stride;
-  if (st0 != kOk) return;  // the index pass already decided this unit
+  // (the index pass already decided every other unit; kNeedsWindow: the ring instantiation passed it on)
+  if (st0 != (prm.second ? kNeedsWindow : kOk)) return;
   if (total == 0) return;
-  if (D2_WINDOW < kMaxBlockLen && total > D2_WINDOW) {
-    if (tid == 0) prm.status[u] = kNeedsOnePass;
-    return;
-  }
+  if (!RING && st0 == kNeedsWindow && tid == 0) prm.status[u] = kOk;  // (mine now; a failure below overwrites it)
 
   // ... then, knowing only where the unit lies: its first bytes (the varint of a raw unit, the first
   // tag), the first index entries and the first 4 KiB of the stream.  The ring is laid out from the
@@ -307,9 +318,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     uint32_t s0 = rd(0u), s1 = rd(1u), s2 = rd(2u);
     uint32_t v0 = __funnelshift_r(s0, s1, sh8), v1 = __funnelshift_r(s1, s2, sh8);
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[L > j ? dst + j : sink + j] = (uint8_t)(v0 >> (8 * j));
+    for (uint32_t j = 0; j < 4; j++) s_out[L > j ? wa(dst + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? dst + 4 + j : sink + j] = (uint8_t)(v1 >> (8 * j));
+    for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? wa(dst + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
     for (uint32_t k = 8; ballot(L > k); k += 8) {  // longer elements: 8 more bytes per trip
       s0 = s2;
       s1 = rd(k / 4 + 1);
@@ -317,10 +328,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       v0 = __funnelshift_r(s0, s1, sh8);
       v1 = __funnelshift_r(s1, s2, sh8);
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? dst + k + j : sink + j] = (uint8_t)(v0 >> (8 * j));
+      for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? wa(dst + k + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++)
-        s_out[L > k + 4 + j ? dst + k + 4 + j : sink + j] = (uint8_t)(v1 >> (8 * j));
+        s_out[L > k + 4 + j ? wa(dst + k + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
     }
   };
   auto ring_al = [&](uint32_t q) -> uint32_t {  // aligned dword that holds stream byte q - shift
@@ -410,6 +421,23 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       }
     }
   }
+  // ---- ring window: is the unit one for it? (three consecutive steps' output must fit, see above) ----
+  uint32_t flushed = 0;  // (ring) every output byte below this has been written to HBM ...
+  uint32_t far_lo = 0;   // ... and below this, a step earlier: visible to the whole workgroup
+  uint32_t ring_lo = 0;  // what this step leaves of the ring: positions from here on (<= far_lo)
+  if (RING) {
+    bool wide = ((uintptr_t)gout & 15) != 0;  // (the ring is flushed in aligned 16-byte pieces)
+    if (tid <= n_chunks && tid < kMaxSteps) {
+      const uint32_t hi = s_sbase[tid + 1 <= n_chunks ? tid + 1 : n_chunks];
+      const uint32_t lo = tid >= 2 ? s_sbase[tid - 2] & ~15u : 0;
+      wide = wide || hi - lo > WIN;
+    }
+    if (__syncthreads_or(wide)) {
+      if (tid == 0) prm.status[u] = kNeedsWindow;
+      return;
+    }
+  }
+  bool passed_on = false;
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
 
@@ -433,6 +461,21 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       }
     }
     const unsigned long long tm0 = SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0;
+    if (RING) {
+      // the last barrier made everything below s_sbase[s - 1] final (the list of step s - 2 is resolved) and
+      // the previous step's flush visible
+      far_lo = flushed;
+      const uint32_t hi = readfirst(s_sbase[s + 1 <= n_chunks ? s + 1 : n_chunks]);
+      if (hi - far_lo > WIN) {  // (after a fast-forward the steps are not consecutive: checked again here)
+        passed_on = true;
+        break;
+      }
+      ring_lo = hi > WIN ? hi - WIN : 0;  // (nothing this step writes lies at or beyond hi)
+      const uint32_t upto = s >= 1 ? readfirst(s_sbase[s - 1]) & ~15u : 0;
+      for (uint32_t i = flushed + tid * 16; i < upto; i += kD2Threads * 16)
+        *reinterpret_cast<uint4*>(gout + i) = *reinterpret_cast<const uint4*>(s_out + wa(i));
+      flushed = upto > flushed ? upto : flushed;
+    }
     // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
     // everything fetched during the previous step is consumed here, BEFORE new loads are issued
     // (the empty asm pins the wait to this point)
@@ -551,10 +594,10 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         // unaligned LDS dword store costs 10-20 aligned ones), eight pieces per lane in flight
         const uint32_t head = (16 - (ed & 15)) & 15;
         const uint32_t hd = head < eL ? head : eL;
-        if (lane < hd) s_out[ed + lane] = in0[es + lane];
+        if (lane < hd) s_out[wa(ed + lane)] = in0[es + lane];
         const uint32_t body = (eL - hd) & ~15u;
         const uint8_t* src = in0 + es + hd;
-        uint8_t* dstp = s_out + ed + hd;  // 16-byte aligned when body > 0
+        const uint32_t dst0 = ed + hd;  // 16-byte aligned when body > 0 (a piece never straddles the ring's end)
         for (uint32_t i = lane * 16; i < body; i += 8 * 1024) {
           // (loads from clamped addresses instead of guarded ones: no private array, no spills; a
           // clamped piece rewrites piece i with its own bytes)
@@ -565,9 +608,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
 #pragma unroll
           for (int j = 0; j < 8; j++) __builtin_memcpy(&v[j], src + ix[j], 16);
 #pragma unroll
-          for (int j = 0; j < 8; j++) *reinterpret_cast<uint4*>(dstp + ix[j]) = v[j];
+          for (int j = 0; j < 8; j++) *reinterpret_cast<uint4*>(s_out + wa(dst0 + ix[j])) = v[j];
         }
-        if (hd + body + lane < eL) s_out[ed + hd + body + lane] = in0[es + hd + body + lane];
+        if (hd + body + lane < eL) s_out[wa(ed + hd + body + lane)] = in0[es + hd + body + lane];
       }
       if (ballot(bad) && lane == 0) s_err = 1;
       __builtin_amdgcn_s_setprio(0);
@@ -712,6 +755,33 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           }
         }
         cbar();
+        // (ring) sources that have left the window: from HBM, where they were written at least a step ago
+        // (device-scope loads: past this CU's vector cache, which may hold the line's older state)
+        uint32_t far_m = 0, far_v = 0;
+        if (RING) {
+          bool fj[B];
+          bool anyfar = false;
+#pragma unroll
+          for (uint32_t j = 0; j < B; j++) {
+            fj[j] = cp[j] && sp[j] < ring_lo;
+            anyfar = anyfar || fj[j];
+          }
+          if (__builtin_expect(ballot(anyfar) != 0, 0)) {
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++) {
+              const uint32_t b = __hip_atomic_load(gout + (fj[j] ? sp[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              far_m |= fj[j] ? 0xffu << (8 * j) : 0;
+              far_v |= fj[j] ? b << (8 * j) : 0;
+              sp[j] = fj[j] ? p + j : sp[j];  // (its window read below: anything inside the window)
+            }
+          }
+          // A run is extended inside the window without wrapping: its first source and its last store
+          // must lie in one lap of the ring, above far_lo.  (Otherwise group by group, like any other.)
+          if (run_end > g + kGroup) {
+            const uint32_t lo = g >= run_off + 1024 ? g - run_off - 1024 : 0;  // (below every source it reads)
+            if (lo < ring_lo || (lo & ~(WIN - 1)) != ((run_end + 16) & ~(WIN - 1))) run_end = 0;
+          }
+        }
         // how many of the groups after mine are skipped: I publish them with mine
         uint32_t nskip = 0;
         // (only looked into when the next group starts inside a long literal)
@@ -735,12 +805,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
         const bool any_partial = ballot(!full && any4) != 0;
         lds_u8* const wo = (lds_u8*)s_out;
         // (complete LDS addresses: the window does not start at LDS address 0)
-        uint32_t a0 = (uint32_t)(uintptr_t)(wo + sp[0]), a1 = (uint32_t)(uintptr_t)(wo + sp[1]);
-        uint32_t a2 = (uint32_t)(uintptr_t)(wo + sp[2]), a3 = (uint32_t)(uintptr_t)(wo + sp[3]);
-        uint32_t ad = (uint32_t)(uintptr_t)(wo + ((full && any4) ? p : sink));
+        uint32_t a0 = (uint32_t)(uintptr_t)(wo + wa(sp[0])), a1 = (uint32_t)(uintptr_t)(wo + wa(sp[1]));
+        uint32_t a2 = (uint32_t)(uintptr_t)(wo + wa(sp[2])), a3 = (uint32_t)(uintptr_t)(wo + wa(sp[3]));
+        uint32_t ad = (uint32_t)(uintptr_t)(wo + ((full && any4) ? wa(p) : sink));
         uint32_t front_after = g + kGroup * (1 + nskip);
         front_after = front_after < cn ? front_after : cn;
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(ad), "+s"(front_after));
+        if (RING) asm volatile("" : "+v"(far_m), "+v"(far_v));  // (the loads have landed before the wait)
         // ---- my turn: every group below mine has published, i.e. everything below g is final ------
         const uint32_t expect = g > cb ? g : cb;
         // (from here to the publish this wave is, or is about to be, on the step's critical path)
@@ -762,12 +833,13 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           // every source is final now: gather (most groups would have to fetch again after an early
           // gather anyway)
           auto at = [](uint32_t a) { return (const lds_u8*)(uintptr_t)a; };
-          const uint32_t v = (uint32_t)*at(a0) | ((uint32_t)*at(a1) << 8) | ((uint32_t)*at(a2) << 16) | ((uint32_t)*at(a3) << 24);
+          uint32_t v = (uint32_t)*at(a0) | ((uint32_t)*at(a1) << 8) | ((uint32_t)*at(a2) << 16) | ((uint32_t)*at(a3) << 24);
+          if (RING) v = (v & ~far_m) | far_v;
           *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)ad = v;
           if (any_partial) {
 #pragma unroll
             for (uint32_t j = 0; j < B; j++)
-              wo[(!full && cp[j]) ? p + j : sink + j] = (uint8_t)(v >> (8 * j));
+              wo[(!full && cp[j]) ? wa(p + j) : sink + j] = (uint8_t)(v >> (8 * j));
           }
         }
         if (__builtin_expect(run_end > g + kGroup, 0)) {
@@ -776,7 +848,8 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
           acc_a++;
           static_assert(B == 4, "extend_run copies one dword per lane in its first loop");
           cbar();
-          extend_run((lds_u8*)s_out, g, run_end, run_off, lane);
+          // (ring: window addresses of one lap, see above)
+          extend_run((lds_u8*)s_out, wa(g), wa(g) + (run_end - g), run_off, lane);
           cbar();
           nskip = 0;
           for (;;) {
@@ -799,7 +872,9 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
     const unsigned long long tm1 = SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0;
     // Workgroup barrier for LDS traffic only: __syncthreads() would also drain vmcnt, i.e. wait
     // for the global prefetches that are meant to stay in flight across the barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (ring: the flush stores of this step must have reached the L2 before the step after next reads them)
+    if (RING) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (SNAPPY_STATS(prm)) {
       tm_work += tm1 - tm0;
       tm_bar += __builtin_amdgcn_s_memtime() - tm1;
@@ -822,6 +897,20 @@ __global__ __launch_bounds__(kD2Threads) void decode_indexed_kernel(Decode2Param
       if (s_err & 1) prm.out_len[u] = 0;  // (a failed unit reports no bytes, like the one-pass kernel)
     }
     return;
+  }
+  if (RING) {
+    if (passed_on) {  // (uniform: decided from s_sbase; what was flushed so far is rewritten by the other instantiation)
+      if (tid == 0) prm.status[u] = kNeedsWindow;
+      return;
+    }
+    for (uint32_t i = flushed + tid * 16; i < total; i += kD2Threads * 16) {
+      if (i + 16 <= total) {
+        *reinterpret_cast<uint4*>(gout + i) = *reinterpret_cast<const uint4*>(s_out + wa(i));
+      } else {
+        for (uint32_t k = i; k < total; k++) gout[k] = s_out[wa(k)];
+      }
+    }
+    return;  // (no CRC from a ring: crc_done stays 0)
   }
   if (SNAPPY_DBG(prm) & 8) return;
   if (((uintptr_t)gout & 15) == 0) {

@@ -109,6 +109,7 @@ struct DeviceGuard {
 
 }  // namespace
 
+constexpr int kTimeSlots = 10;  // snappy_hip_ctx_kernel_ms(which)
 struct snappy_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -124,8 +125,8 @@ struct snappy_hip_ctx {
     int which;
   };
   std::vector<Timed> timed;
-  double ms_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t ms_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double ms_sum[kTimeSlots] = {};
+  uint64_t ms_cnt[kTimeSlots] = {};
 };
 
 namespace {
@@ -230,8 +231,10 @@ namespace {
 int ctx_init(snappy_hip_ctx* c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
-  HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOutAlloc + 8192));
+  HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
+  HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kRingWin>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kRingWin) + 8192));
   std::vector<uint32_t> tab(1024), mul(kCrcThreads), so(kSeqLen), ss(kSeqLen);
   build_crc_tables(tab.data(), mul.data());
   {
@@ -304,7 +307,7 @@ extern "C" int snappy_hip_ctx_timing(snappy_hip_ctx* c, int enable) {
       (void)hipEventDestroy(t.b);
     }
     c->timed.clear();
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < kTimeSlots; i++) {
       c->ms_sum[i] = 0;
       c->ms_cnt[i] = 0;
     }
@@ -324,7 +327,7 @@ extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_
     (void)hipEventDestroy(t.b);
   }
   c->timed.clear();
-  if (which < 0 || which > 7) return 0;
+  if (which < 0 || which >= kTimeSlots) return 0;
   if (launches) *launches = c->ms_cnt[which];
   return c->ms_cnt[which] ? c->ms_sum[which] / (double)c->ms_cnt[which] : 0.0;
 }
@@ -579,10 +582,19 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       fprintf(stderr, "index verify: %d units with a mismatch\n", shown);
       (void)hipFree(d_rep);
     }
-    {
+    // Without the fused CRC (which needs the whole block in the window): the ring-window instantiation,
+    // three workgroups per CU; then the whole-block one over the units it passed on (a workgroup of any
+    // other unit leaves at once).  kD2RingFirst == 0 / SNAPPY_HIP_NO_RING (debug builds): whole-block only.
+    const bool ring_first = kD2RingFirst && dp.crc == nullptr && !dbg_env("SNAPPY_HIP_NO_RING");
+    if (ring_first) {
       LaunchTimer lt(c, s, 0);
-      LAUNCH(decode_indexed_kernel, dim3((uint32_t)n_units), dim3(kD2Threads),
-                         kOutAlloc + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
+      LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), out_alloc(kRingWin), s, dp);
+    }
+    {
+      LaunchTimer lt(c, s, ring_first ? 8 : 0);
+      dp.second = ring_first ? 1 : 0;
+      LAUNCH(decode_indexed_kernel<kMaxBlockLen>, dim3((uint32_t)n_units), dim3(kD2Threads),
+             out_alloc(kMaxBlockLen) + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
     }
     if (d_stats) {
       unsigned long long h[16];
@@ -1342,7 +1354,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   constexpr int kMaxRounds = 64;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
   void* base;
-  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
+  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
   unsigned long long* nxt[2];
@@ -1358,12 +1370,15 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   q += (size_t)nseg * 4;
   uint32_t* reached = (uint32_t*)q;
   q += (size_t)nseg * 4;
+  uint32_t* follow = (uint32_t*)q;
+  q += (size_t)nseg * 4;
   uint32_t* changed = (uint32_t*)q;  // one block of 128 words per round: [0] entries changed, [64] a claim cut
   q += 128 * 4 * 0;                  // (rounds share the block: each round's words are read before the next look)
   q += 128 * 4;
   uint32_t* flags = (uint32_t*)q;
   HIP_TRY(hipMemsetAsync(nxt[0], 0xff, (size_t)nseg * 16, s));  // both buffers: nobody has claimed anything
   HIP_TRY(hipMemsetAsync(prev, 0xff, (size_t)nseg * 4, s));
+  HIP_TRY(hipMemsetAsync(follow, 0xff, (size_t)nseg * 4, s));
   HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4 + 16, s));
   SplitParams sp{};
   sp.in = d_tags;
@@ -1372,6 +1387,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.prev = prev;
   sp.outb = outb;
   sp.memo = memo;
+  sp.follow = follow;
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;

@@ -29,6 +29,9 @@ constexpr uint32_t kSplitSeg = 256;      // stream bytes per lane
 // Streams with longer literals converge slowly or not at all within the round limit: serial walk.)
 constexpr uint32_t kSplitMaxCover = 65536 / kSplitSeg + 1;
 constexpr uint32_t kSplitClean = 16;  // native elements in a row that make a walk trusted (see the kernel)
+// Follow-through (see the end of split_walk_kernel): literals at least this long, at most so many in a row
+constexpr uint32_t kSplitFollowMin = 1024;
+constexpr uint32_t kSplitFollowMax = 1u << 16;
 
 struct SplitParams {
   const uint8_t* in;      // the tag stream (behind the varint)
@@ -39,6 +42,7 @@ struct SplitParams {
   uint32_t* prev;         // [nseg] the entry used in the previous round (bit 31: it was a claimed one)
   uint32_t* outb;         // [nseg] output bytes of the elements that start in the segment
   uint32_t* memo;         // [nseg] the last walk's exit ([0:31), all ones = invalid element) and trust (bit 31)
+  uint32_t* follow;       // [nseg] the entry from which somebody has walked this segment's chain of long literals
   uint32_t* changed;      // entries that changed this round
   uint32_t* flags;        // [1] invalid element met, [2] an element straddles a 64 KiB boundary of the output
   // locate pass
@@ -164,6 +168,33 @@ __global__ __launch_bounds__(kSplitWg) void split_walk_kernel(SplitParams p) {
   (void)t_all;
   const unsigned long long key = ((unsigned long long)s << 32) | pos;
   for (uint32_t t = s + 1; t <= t_hi; t++) atomicMin(&p.nxt_out[t], key);
+  // Follow-through.  Long literals back to back (incompressible blocks: one literal of 64 KiB each) are a
+  // chain that would advance ONE literal per round -- the segment a literal ends in learns its entry from
+  // the walk of the segment the literal starts in.  So a trusted fresh walk that lands on a long literal
+  // does that segment's walk as well (it is that one element), in that segment's name -- the same keys its
+  // own lane writes from the next round on -- and goes on while it keeps landing on long literals.
+  // `follow` keeps later walks from doing the same chain again.
+  if (same || clean < kSplitClean || p.follow[s] == e) return;
+  uint32_t from = s, p0 = pos;
+  for (uint32_t hop = 0; hop < kSplitFollowMax; hop++) {
+    const uint32_t T = p0 / kSplitSeg;
+    if (p0 >= p.n || T <= from || T > from + kSplitMaxCover) break;  // (beyond the cover T's entry was not claimed)
+    uint32_t b[5];
+#pragma unroll
+    for (uint32_t i = 0; i < 5; i++) b[i] = p0 + i < p.n ? p.in[p0 + i] : 0;
+    uint32_t L, size;
+    if (!decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), p.n - p0 - 1, &L, &size)) break;
+    if ((b[0] & 3) != 0 || (b[0] >> 2) >= 62 || size < kSplitFollowMin) break;  // not a block encoder's long literal
+    const uint32_t p1 = p0 + size;  // (> the end of segment T: T's walk is this element)
+    uint32_t T1 = p1 / kSplitSeg;
+    T1 = T1 < p.nseg - 1 ? T1 : p.nseg - 1;
+    T1 = T1 < T + kSplitMaxCover ? T1 : T + kSplitMaxCover;
+    const unsigned long long k2 = ((unsigned long long)T << 32) | p1;
+    for (uint32_t t = T + 1; t <= T1; t++) atomicMin(&p.nxt_out[t], k2);
+    p.follow[T] = p0;
+    from = T;
+    p0 = p1;
+  }
 }
 
 // Is the state the right one?  Independent of how it was reached: the walked segments must form ONE

@@ -567,3 +567,116 @@ def test_shards_from_one_process_land_in_one_host_buffer(hip, orc, torch_mod):
     assert json.loads(rc.stdout.strip().splitlines()[-1])["equals_oracle"] is True
     for c in ctxs:
         c.close()
+
+
+def _ring_stream(rng, target, style):
+    """One block's tag stream for the ring-window decoder (decode2_kernel.h): short literals and copies at
+    a text-like ratio (so that three steps' output fits the ring), with copies whose sources lie further
+    back than the ring holds, long literals, runs of same-offset copies, and -- style 'dense' -- stretches
+    of pure copies that make three steps' output outgrow the ring in the middle of the block."""
+    out, body = bytearray(), bytearray()
+
+    def lit(n):
+        data = rng.randbytes(n)
+        m = n - 1
+        if m < 60:
+            body.append(m << 2)
+        else:
+            ll = max((m.bit_length() + 7) // 8, 1)
+            body.extend(bytes([(59 + ll) << 2]) + m.to_bytes(ll, "little"))
+        body.extend(data)
+        out.extend(data)
+
+    def copy(off, ln):
+        if 4 <= ln <= 11 and off < 2048 and rng.random() < 0.5:
+            body.extend(bytes([((off >> 8) << 5) | ((ln - 4) << 2) | 1, off & 0xff]))
+        else:
+            body.extend(bytes([((ln - 1) << 2) | 2]) + off.to_bytes(2, "little"))
+        for _ in range(ln):
+            out.append(out[-off])
+
+    lit(rng.randint(1, 60))
+    while len(out) < target:
+        r = rng.random()
+        room = target - len(out)
+        if style == "dense" and 20000 < len(out) < 45000:
+            copy(rng.randint(1, min(len(out), 65535)), min(room, 64))
+        elif r < 0.45:
+            lit(min(room, rng.randint(1, 40)))
+        elif r < 0.47:
+            lit(min(room, rng.choice([61, 100, 700, 3000, 9000])))
+        elif r < 0.472 and style == "biglit":
+            lit(min(room, rng.randint(15000, 40000)))
+        elif r < 0.49:  # a run: one offset, copy after copy (also offsets from before the ring)
+            off = rng.choice([1, 2, 7, 44, 300, 5000, min(len(out), 40000)])
+            off = min(off, len(out))
+            for _ in range(rng.randint(3, 120)):
+                if len(out) >= target:
+                    break
+                copy(off, min(target - len(out), 64))
+        else:
+            far = rng.random() < 0.25
+            off = rng.randint(min(len(out), 30000), min(len(out), 65535)) if far else rng.randint(1, min(len(out), 3000))
+            copy(off, min(room, rng.randint(4, 40)))
+    return bytes(body), bytes(out)
+
+
+def test_ring_window_decoder(hip, orc, torch_mod):
+    """the indexed decoder's two instantiations (ring of the last 32 KiB first, whole block for the units it
+    passes on; whole block only when the CRC comes out of the decode kernel): foreign streams whose copies
+    reach behind the ring, wrap it, run across its end; outputs at unaligned addresses"""
+    torch = torch_mod
+    rng = random.Random(99)
+    units = []
+    for i in range(240):
+        style = ("text", "biglit", "dense", "text")[i % 4]
+        target = 65536 if i % 3 else rng.randint(33000, 65536)
+        body, plain = _ring_stream(rng, target, style)
+        units.append((body, plain))
+    for b, p in units[:12]:
+        assert orc.decode_all_tags(b, len(p)) == (0, p)
+    n = len(units)
+    # more units than one wave of workgroups: copies of the same streams, different placements
+    reps = 6
+    in_off, out_off, pos, opos = [], [], 0, 0
+    for r in range(reps):
+        for k, (b, p) in enumerate(units):
+            in_off.append(pos)
+            pos += len(b) + rng.randint(0, 5)
+            opos += 0 if (k + r) % 5 == 0 else rng.randint(1, 15)  # (16-byte aligned or not)
+            if (k + r) % 5 == 0:
+                opos = (opos + 15) & ~15
+            out_off.append(opos)
+            opos += len(p)
+    stream = np.zeros(pos + 64, np.uint8)
+    for j, o in enumerate(in_off):
+        b = units[j % n][0]
+        stream[o:o + len(b)] = np.frombuffer(b, np.uint8)
+    nu = n * reps
+    ctx = hip.Context(0)
+    d_stream = _dev(torch, stream)
+    d_in_off = _dev(torch, np.array(in_off, np.int64))
+    d_in_len = _dev(torch, np.array([len(units[j % n][0]) for j in range(nu)], np.int32))
+    d_out_off = _dev(torch, np.array(out_off, np.int64))
+    d_out_cap = _dev(torch, np.array([len(units[j % n][1]) for j in range(nu)], np.int32))
+    want = np.zeros(opos, np.uint8)
+    for j, o in enumerate(out_off):
+        p = units[j % n][1]
+        want[o:o + len(p)] = np.frombuffer(p, np.uint8)
+    for with_crc in (False, True):
+        d_out_len = torch.zeros(nu, dtype=torch.int32, device="cuda")
+        d_status = torch.full((nu,), 77, dtype=torch.int32, device="cuda")
+        d_dec = torch.zeros(opos, dtype=torch.uint8, device="cuda")
+        d_crc = torch.zeros(nu, dtype=torch.int32, device="cuda") if with_crc else None
+        ctx.decode_blocks(d_stream, d_in_off, d_in_len, nu, d_dec, d_out_off, d_out_cap, d_out_len, d_status,
+                          unit=hip.UNIT_BODY, d_crc=d_crc)
+        ctx.sync()
+        st = d_status.cpu().numpy()
+        assert (st == 0).all(), (with_crc, np.nonzero(st)[0][:10], st[st != 0][:10])
+        got = d_dec.cpu().numpy()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (with_crc, bad[:10], np.searchsorted(np.array(out_off), bad[:3], side="right") - 1)
+        if with_crc:
+            crcs = d_crc.cpu().numpy().view(np.uint32)
+            for j in range(0, nu, 97):
+                assert int(crcs[j]) == orc.masked_crc(units[j % n][1])

@@ -377,3 +377,16 @@ def test_random_multi_block_raw_buffers(hip, orc):
         body, plain = _random_stream(rng, rng.choice([200000, 500000]), far=True)
         raw = _varint(len(plain)) + body
         assert hip.decode(raw) == orc.decode(raw) == plain, i
+    # long literals back to back (every incompressible block is one): the walk that lands on one follows
+    # the chain (split_kernels.h); alone, in stretches between text, and with a bit flipped in a length byte
+    big = [rng.randbytes(6 << 20),
+           b"".join(text[:rng.randint(1, 200000)] + rng.randbytes(rng.randint(1, 400000)) for _ in range(12)),
+           rng.randbytes(65536 * 3 + 17) + text[:70000] + rng.randbytes(65536 * 20)]
+    for i, src in enumerate(big):
+        comp = orc.encode(src)
+        assert hip.decode(comp) == src, i
+        at = comp.find(b"\xf4\xff\xff", len(comp) // 2)
+        if at > 0:
+            bad = bytearray(comp)
+            bad[at + 2] ^= 0x10  # the literal is 4096 bytes shorter than the encoder said
+            assert hip.decode(bytes(bad)) == orc.decode(bytes(bad)), i

@@ -32,6 +32,8 @@ for cls in classes:
             ctx.sync()
             ms, n = ctx.kernel_ms(0)
             ims, _ = ctx.kernel_ms(4)
+            ms8, _ = ctx.kernel_ms(8)
             ctx.timing(False)
         print(cls, "dbg", dbg, "ms %.3f" % ms, "index ms %.3f" % ims, "per-block us (512 concurrent) %.1f" % (ms * 1e3 * 512 / nb),
-              "C/block %d" % (tot // nb), flush=True)
+              "C/block %d" % (tot // nb), "second launch ms %.3f" % ms8,
+              "ok" if bool((d_out == d_in).all().item()) and int(d_status.abs().sum().item()) == 0 else "WRONG", flush=True)

@@ -6,8 +6,9 @@ import numpy as np, torch
 hip = importlib.import_module("nim-snappy_amd")
 import corpus
 ctx = hip.Context(0)
-for nb, only in ((1024, None), (1024, "T_TEXT"), (1024, "R"), (16384, None)):
-    src = corpus.make_blocks(0, nb, only=only).tobytes()
+for nb, only in ((1024, None), (1024, "T_TEXT"), (1024, "R"), (1024, "T_TEXT+R"), (16384, None), (16384, "R")):
+    mix = [50, 0, 0, 50, 0, 0, 0] if only == "T_TEXT+R" else None
+    src = corpus.make_blocks(0, nb, only=None if mix else only, mix=mix).tobytes()
     raw = hip.encode(src)
     d_in = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
     d_out = torch.empty(len(src), dtype=torch.uint8, device="cuda")
