@@ -127,13 +127,12 @@ __global__ __launch_bounds__(kSplitWg) void split_walk_kernel(SplitParams p) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
-  if (!live) return;
-  if (same) {  // same entry as last round: same walk, same result
+  if (live && same) {  // same entry as last round: same walk, same result
     const uint32_t m = p.memo[s];
     pos = m & 0x7fffffffu;
     clean = (m >> 31) ? kSplitClean : 0;
     bad = pos == 0x7fffffffu;
-  } else {
+  } else if (live) {
     while (pos < seg_hi) {
       uint32_t L, size, tg;
       if (!split_element(stage, wg_lo, p.n, pos, &L, &size, &tg)) {
@@ -150,50 +149,66 @@ __global__ __launch_bounds__(kSplitWg) void split_walk_kernel(SplitParams p) {
       pos += size;
     }
   }
-  if (p.locate) {
-    if (bad && e < seg_hi) p.flags[1] = 1;
+  if (p.locate) {  // (uniform)
+    if (live && bad && e < seg_hi) p.flags[1] = 1;
     return;
   }
-  if (!same) {
+  if (live && !same) {
     p.outb[s] = e < seg_hi ? out : 0;
     p.memo[s] = bad ? 0x7fffffffu : (pos | (clean >= kSplitClean ? 0x80000000u : 0u));
   }
-  if (bad || e >= seg_hi) return;  // (a segment the chain passes over claims nothing)
-  // the chain leaves at pos: that is the entry of every segment up to the one that holds it
-  uint32_t t_hi = pos / kSplitSeg;
-  t_hi = t_hi < p.nseg - 1 ? t_hi : p.nseg - 1;
-  const uint32_t t_all = t_hi;
-  t_hi = t_hi < s + kSplitMaxCover ? t_hi : s + kSplitMaxCover;
-  if (clean < kSplitClean) t_hi = t_hi < s + 1 ? t_hi : s + 1;
-  (void)t_all;
-  const unsigned long long key = ((unsigned long long)s << 32) | pos;
-  for (uint32_t t = s + 1; t <= t_hi; t++) atomicMin(&p.nxt_out[t], key);
+  // (no lane leaves before the end: the follow-through below is the whole wave's work)
+  const bool claims = live && !bad && e < seg_hi;  // (a segment the chain passes over claims nothing)
+  if (claims) {
+    // the chain leaves at pos: that is the entry of every segment up to the one that holds it
+    uint32_t t_hi = pos / kSplitSeg;
+    t_hi = t_hi < p.nseg - 1 ? t_hi : p.nseg - 1;
+    t_hi = t_hi < s + kSplitMaxCover ? t_hi : s + kSplitMaxCover;
+    if (clean < kSplitClean) t_hi = t_hi < s + 1 ? t_hi : s + 1;
+    const unsigned long long key = ((unsigned long long)s << 32) | pos;
+    for (uint32_t t = s + 1; t <= t_hi; t++) atomicMin(&p.nxt_out[t], key);
+  }
   // Follow-through.  Long literals back to back (incompressible blocks: one literal of 64 KiB each) are a
   // chain that would advance ONE literal per round -- the segment a literal ends in learns its entry from
   // the walk of the segment the literal starts in.  So a trusted fresh walk that lands on a long literal
   // does that segment's walk as well (it is that one element), in that segment's name -- the same keys its
-  // own lane writes from the next round on -- and goes on while it keeps landing on long literals.
+  // own lane writes from the next round on -- and goes on while it keeps landing on long literals: one
+  // trip to memory for the literal's header per hop, the claims are written by the whole wave.
   // `follow` keeps later walks from doing the same chain again.
-  if (same || clean < kSplitClean || p.follow[s] == e) return;
-  uint32_t from = s, p0 = pos;
-  for (uint32_t hop = 0; hop < kSplitFollowMax; hop++) {
-    const uint32_t T = p0 / kSplitSeg;
-    if (p0 >= p.n || T <= from || T > from + kSplitMaxCover) break;  // (beyond the cover T's entry was not claimed)
-    uint32_t b[5];
+  bool fol = claims && !same && clean >= kSplitClean && p.follow[s] != e;
+  uint32_t from = s, p0 = pos, hops = 0;
+  while (__ballot(fol)) {
+    uint32_t T = 0, T1 = 0, p1 = 0;
+    bool go = false;
+    if (fol) {
+      T = p0 / kSplitSeg;
+      // (beyond the cover T's entry was not claimed)
+      if (p0 < p.n && T > from && T <= from + kSplitMaxCover && hops < kSplitFollowMax) {
+        uint32_t b[5];
 #pragma unroll
-    for (uint32_t i = 0; i < 5; i++) b[i] = p0 + i < p.n ? p.in[p0 + i] : 0;
-    uint32_t L, size;
-    if (!decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), p.n - p0 - 1, &L, &size)) break;
-    if ((b[0] & 3) != 0 || (b[0] >> 2) >= 62 || size < kSplitFollowMin) break;  // not a block encoder's long literal
-    const uint32_t p1 = p0 + size;  // (> the end of segment T: T's walk is this element)
-    uint32_t T1 = p1 / kSplitSeg;
-    T1 = T1 < p.nseg - 1 ? T1 : p.nseg - 1;
-    T1 = T1 < T + kSplitMaxCover ? T1 : T + kSplitMaxCover;
-    const unsigned long long k2 = ((unsigned long long)T << 32) | p1;
-    for (uint32_t t = T + 1; t <= T1; t++) atomicMin(&p.nxt_out[t], k2);
-    p.follow[T] = p0;
-    from = T;
-    p0 = p1;
+        for (uint32_t i = 0; i < 5; i++) b[i] = p0 + i < p.n ? p.in[p0 + i] : 0;
+        uint32_t L, size;
+        go = decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), p.n - p0 - 1, &L, &size) &&
+             (b[0] & 3) == 0 && (b[0] >> 2) < 62 && size >= kSplitFollowMin;  // a block encoder's long literal
+        p1 = p0 + size;  // (> the end of segment T: T's walk is this element)
+        T1 = p1 / kSplitSeg;
+        T1 = T1 < p.nseg - 1 ? T1 : p.nseg - 1;
+        T1 = T1 < T + kSplitMaxCover ? T1 : T + kSplitMaxCover;
+      }
+      fol = go;
+    }
+    for (uint64_t m = __ballot(go); m; m &= m - 1) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      const uint32_t bT = readlane(T, l), bT1 = readlane(T1, l), bp1 = readlane(p1, l);
+      const unsigned long long k2 = ((unsigned long long)bT << 32) | bp1;
+      for (uint32_t t = bT + 1 + threadIdx.x; t <= bT1; t += kSplitWg) atomicMin(&p.nxt_out[t], k2);
+    }
+    if (go) {
+      p.follow[T] = p0;
+      from = T;
+      p0 = p1;
+      hops++;
+    }
   }
 }
 
