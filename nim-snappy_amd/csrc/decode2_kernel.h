@@ -54,6 +54,10 @@ constexpr uint32_t kRingWin = 32768;
 #define D2_RING 1  // (0: experiments, the whole-block instantiation only)
 #endif
 constexpr bool kD2RingFirst = D2_RING != 0;
+#ifndef D2_RING_CATCHUPS
+#define D2_RING_CATCHUPS 2
+#endif
+constexpr uint32_t kRingCatchUps = D2_RING_CATCHUPS;  // wide steps (see the kernel) a unit may have in the ring
 // dynamic LDS of a launch: the window and 64 scratch dwords behind it, one per lane (no bank conflicts)
 constexpr uint32_t out_alloc(uint32_t win) { return win + 256; }
 constexpr uint32_t kMaxSteps = kMaxFastIn / kChunk + 2;
@@ -103,9 +107,14 @@ __device__ __forceinline__ void decode_fast(uint32_t tag, uint32_t b14, bool* is
 
 // The copy loops of a run extension (see the resolver), out of line: they are cold for text-like
 // data, and keeping them out of the resolver's loop keeps that loop's code and registers tight.
+// MASK: window address of output byte x = x & MASK (all ones: the window holds the whole block; the ring
+// wraps, and a source's five dwords may lie on both sides of its end: each is addressed on its own).
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+template <uint32_t MASK>
 __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, uint32_t run_end, uint32_t run_off,
                                                      uint32_t lane) {
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  auto rd = [&](uint32_t a) -> uint32_t { return *reinterpret_cast<const lds_u32*>(out + (a & MASK)); };  // a: 4-aligned
   // W = the smallest multiple of the offset that is >= kGroup: then W - offset < kGroup, i.e. for
   // x >= g + kGroup the source x - W is not below g - offset, the first byte the run's own chain of
   // copies reaches from x (a larger multiple could read bytes from before the run)
@@ -117,18 +126,13 @@ __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, ui
   x1 = x1 > g + kGroup ? x1 : g + kGroup;
   x1 = x1 < run_end ? x1 : run_end;
   for (uint32_t x = g + kGroup + 4 * lane; x < x1; x += kGroup) {
-    const uint32_t src = x - W;
-    const __attribute__((address_space(3))) uint32_t* a32 =
-        reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(out + (src & ~3u));
-    *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(out + x) =
-        __funnelshift_r(a32[0], a32[1], (src & 3) * 8);
+    const uint32_t src = x - W, sa = src & ~3u;
+    *reinterpret_cast<lds_u32*>(out + (x & MASK)) = __funnelshift_r(rd(sa), rd(sa + 4), (src & 3) * 8);
   }
   asm volatile("" ::: "memory");
   for (uint32_t x = x1 + 16 * lane; x < run_end; x += 1024) {  // (x1, run_end: multiples of 256)
-    const uint32_t src = x - W4;
-    const __attribute__((address_space(3))) uint32_t* a32 =
-        reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(out + (src & ~3u));
-    const uint32_t r0 = a32[0], r1 = a32[1], r2 = a32[2], r3 = a32[3], r4 = a32[4];
+    const uint32_t src = x - W4, sa = src & ~3u;
+    const uint32_t r0 = rd(sa), r1 = rd(sa + 4), r2 = rd(sa + 8), r3 = rd(sa + 12), r4 = rd(sa + 16);
     const uint32_t sh8 = (src & 3) * 8;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v;
@@ -136,7 +140,7 @@ __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, ui
     v.y = __funnelshift_r(r1, r2, sh8);
     v.z = __funnelshift_r(r2, r3, sh8);
     v.w = __funnelshift_r(r3, r4, sh8);
-    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(out + x) = v;
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(out + (x & MASK)) = v;
   }
 }
 
@@ -426,13 +430,20 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   uint32_t far_lo = 0;   // ... and below this, a step earlier: visible to the whole workgroup
   uint32_t ring_lo = 0;  // what this step leaves of the ring: positions from here on (<= far_lo)
   if (RING) {
+    // (steps that need the catch-up flush in the loop -- three steps do not fit, two do -- cost a barrier and
+    // a trip to the L2 each: a unit with more than a few, e.g. repeated long strings, is better off with the
+    // whole-block window)
     bool wide = ((uintptr_t)gout & 15) != 0;  // (the ring is flushed in aligned 16-byte pieces)
+    bool catch_up = false;
     if (tid <= n_chunks && tid < kMaxSteps) {
       const uint32_t hi = s_sbase[tid + 1 <= n_chunks ? tid + 1 : n_chunks];
-      const uint32_t lo = tid >= 2 ? s_sbase[tid - 2] & ~15u : 0;
+      const uint32_t lo = tid >= 1 ? s_sbase[tid - 1] & ~15u : 0;
+      const uint32_t lo3 = tid >= 2 ? s_sbase[tid - 2] & ~15u : 0;
       wide = wide || hi - lo > WIN;
+      catch_up = hi - lo3 > WIN;
     }
-    if (__syncthreads_or(wide)) {
+    const uint32_t n_catch = __syncthreads_count(catch_up);
+    if (__syncthreads_or(wide) || n_catch > kRingCatchUps) {
       if (tid == 0) prm.status[u] = kNeedsWindow;
       return;
     }
@@ -466,15 +477,26 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       // the previous step's flush visible
       far_lo = flushed;
       const uint32_t hi = readfirst(s_sbase[s + 1 <= n_chunks ? s + 1 : n_chunks]);
-      if (hi - far_lo > WIN) {  // (after a fast-forward the steps are not consecutive: checked again here)
-        passed_on = true;
-        break;
+      const uint32_t upto = s >= 1 ? readfirst(s_sbase[s - 1]) & ~15u : 0;
+      auto flush_to = [&](uint32_t to) {
+        for (uint32_t i = flushed + tid * 16; i < to; i += kD2Threads * 16)
+          *reinterpret_cast<uint4*>(gout + i) = *reinterpret_cast<const uint4*>(s_out + wa(i));
+        flushed = to > flushed ? to : flushed;
+      };
+      if (hi - far_lo > WIN) {
+        // a wide step (a stretch of copies: much output from little stream): what is final now is written
+        // and waited for at once, so that the ring has to hold two steps only -- a wait for the stores
+        // and a barrier, paid by the steps that produce many bytes
+        flush_to(upto);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        far_lo = flushed;
+        if (hi - far_lo > WIN) {  // (after a fast-forward the steps are not consecutive: the check before the loop missed it)
+          passed_on = true;
+          break;
+        }
       }
       ring_lo = hi > WIN ? hi - WIN : 0;  // (nothing this step writes lies at or beyond hi)
-      const uint32_t upto = s >= 1 ? readfirst(s_sbase[s - 1]) & ~15u : 0;
-      for (uint32_t i = flushed + tid * 16; i < upto; i += kD2Threads * 16)
-        *reinterpret_cast<uint4*>(gout + i) = *reinterpret_cast<const uint4*>(s_out + wa(i));
-      flushed = upto > flushed ? upto : flushed;
+      flush_to(upto);
     }
     // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
     // everything fetched during the previous step is consumed here, BEFORE new loads are issued
@@ -775,11 +797,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
               sp[j] = fj[j] ? p + j : sp[j];  // (its window read below: anything inside the window)
             }
           }
-          // A run is extended inside the window without wrapping: its first source and its last store
-          // must lie in one lap of the ring, above far_lo.  (Otherwise group by group, like any other.)
+          // A run is extended inside the ring: its sources must still be there.  (Otherwise group by group,
+          // like any other.)
           if (run_end > g + kGroup) {
             const uint32_t lo = g >= run_off + 1024 ? g - run_off - 1024 : 0;  // (below every source it reads)
-            if (lo < ring_lo || (lo & ~(WIN - 1)) != ((run_end + 16) & ~(WIN - 1))) run_end = 0;
+            if (lo < ring_lo) run_end = 0;
           }
         }
         // how many of the groups after mine are skipped: I publish them with mine
@@ -848,8 +870,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
           acc_a++;
           static_assert(B == 4, "extend_run copies one dword per lane in its first loop");
           cbar();
-          // (ring: window addresses of one lap, see above)
-          extend_run((lds_u8*)s_out, wa(g), wa(g) + (run_end - g), run_off, lane);
+          extend_run<RING ? WIN - 1 : 0xffffffffu>((lds_u8*)s_out, g, run_end, run_off, lane);
           cbar();
           nskip = 0;
           for (;;) {
