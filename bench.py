@@ -13,8 +13,9 @@ workload: configs[1] of BASELINE.json -- 1 x MI355X block DECOMPRESS of 65 536 x
 multi-GPU: every rank owns its own 65 536-block range of the corpus (weak scaling, no data-path
           collective -- blocks are independent); value = all ranks' bytes / max time.
 
-roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel (pass 2
-          of the v2 decoder; pass 1, index_units_kernel, is reported beside it).  achieved =
+roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel<32768> (pass 2
+          of the v2 decoder, ring-window instantiation; pass 1, index_units_kernel, and the whole-block
+          instantiation's launch over the units the ring one passes on are reported beside it).  achieved =
           (sum C + sum U) per launch / average kernel duration, measured with HIP events on the
           launch stream inside the timed region (snappy_hip_ctx_kernel_ms).
           peak = 8000 GB/s (MI355X_MICROARCH.md).
@@ -53,7 +54,7 @@ def measured_traffic(nb, only):
         return None
     with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
         t = json.load(f)
-    k = t.get("kernels", {}).get("decode_indexed_kernel")
+    k = t.get("kernels", {}).get("decode_indexed_kernel<32768>") or t.get("kernels", {}).get("decode_indexed_kernel")
     return None if k is None else k["total_bytes"]
 
 
@@ -486,7 +487,7 @@ def main():
                 "measured_copy_GBps": round(copy_gbps, 1),  # device-to-device copy, read + write
                 "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "traffic": measured_traffic(nb, args.only),
-                "kernel": "decode_indexed_kernel",
+                "kernel": "decode_indexed_kernel<32768>",  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),
                 "index_pass_kernel_ms": round(idx_ms, 4),
                 "passed_on_units_kernel_ms": round(dec2_ms, 4),

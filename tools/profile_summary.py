@@ -2,6 +2,10 @@
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
 def short(k):
+    # the indexed decoder's two instantiations: ring window first, whole-block window for what it passes on
+    for win in ("32768", "65536"):
+        if "decode_indexed_kernel<%s" % win in k or "decode_indexed_kernelILj%s" % win in k:
+            return "decode_indexed_kernel<%s>" % win
     for name in ("decode_indexed_kernel", "index_units_kernel", "decode_units_kernel", "encode_blocks_kernel",
                  "crc32c_units_kernel", "gather_slots_kernel", "scan_sizes_kernel", "region_counts_kernel",
                  "frame_chase_kernel", "frame_stitch_kernel", "frame_fill_kernel", "frame_scatter_kernel",
