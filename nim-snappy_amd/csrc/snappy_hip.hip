@@ -1351,89 +1351,94 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // -1: not applicable (no fixed point within the round limit, an element straddles a block boundary).
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s) {
-  constexpr int kMaxRounds = 64;
+  // rounds before the first look at the chain (text-like data is complete by then), between later looks
+  // (a handful of late candidates), looks before the serial walk takes over
+  constexpr int kRoundsFirst = 4, kRoundsLater = 2, kMaxLooks = 10;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
+  const size_t nodes = (size_t)nseg * kSplitCand;
   void* base;
-  int st = ws_get(c, 13, (size_t)nseg * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 8) + 8 + 2 * 128 * 4 + 64, &base);
+  // per node: ent, ext, ob, two jump tables (4 bytes each), reach (1); per segment: entry, outb (4), out_at (8)
+  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 16 + 8 + 64 + 64, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
-  unsigned long long* nxt[2];
-  nxt[0] = (unsigned long long*)q, q += (size_t)nseg * 8;
-  nxt[1] = (unsigned long long*)q, q += (size_t)nseg * 8;
   uint64_t* out_at = (uint64_t*)q;
   q += ((size_t)nseg + 1) * 8;
-  uint32_t* prev = (uint32_t*)q;
+  uint32_t* ent = (uint32_t*)q;
+  q += nodes * 4;
+  uint32_t* ext = (uint32_t*)q;
+  q += nodes * 4;
+  uint32_t* ob = (uint32_t*)q;
+  q += nodes * 4;
+  uint32_t* jump[2];
+  jump[0] = (uint32_t*)q, q += nodes * 4;
+  jump[1] = (uint32_t*)q, q += nodes * 4;
+  uint32_t* entry = (uint32_t*)q;
   q += (size_t)nseg * 4;
   uint32_t* outb = (uint32_t*)q;
   q += (size_t)nseg * 4;
-  uint32_t* memo = (uint32_t*)q;
-  q += (size_t)nseg * 4;
-  uint32_t* reached = (uint32_t*)q;
-  q += (size_t)nseg * 4;
-  uint32_t* follow = (uint32_t*)q;
-  q += (size_t)nseg * 4;
-  uint32_t* changed = (uint32_t*)q;  // one block of 128 words per round: [0] entries changed, [64] a claim cut
-  q += 128 * 4 * 0;                  // (rounds share the block: each round's words are read before the next look)
-  q += 128 * 4;
+  uint32_t* counters = (uint32_t*)q;  // [0] candidates added, [1] overflow
+  q += 32;
   uint32_t* flags = (uint32_t*)q;
-  HIP_TRY(hipMemsetAsync(nxt[0], 0xff, (size_t)nseg * 16, s));  // both buffers: nobody has claimed anything
-  HIP_TRY(hipMemsetAsync(prev, 0xff, (size_t)nseg * 4, s));
-  HIP_TRY(hipMemsetAsync(follow, 0xff, (size_t)nseg * 4, s));
-  HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4 + 16, s));
+  q += 32;
+  uint8_t* reach = q;
+  HIP_TRY(hipMemsetAsync(ent, 0xff, nodes * 8, s));  // ent and ext: no candidates, nothing walked
+  HIP_TRY(hipMemsetAsync(counters, 0, 64, s));       // and the flags
   SplitParams sp{};
   sp.in = d_tags;
   sp.n = n_tags;
   sp.nseg = nseg;
-  sp.prev = prev;
+  sp.ent = ent;
+  sp.ext = ext;
+  sp.ob = ob;
+  sp.counters = counters;
+  sp.entry = entry;
   sp.outb = outb;
-  sp.memo = memo;
-  sp.follow = follow;
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;
-  const uint32_t grid = (nseg + 255) / 256;            // (the check kernels)
-  const uint32_t wgrid = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 64 KiB of staged stream each)
+  const uint32_t grid = (nseg + 255) / 256;
+  const uint32_t ngrid = (uint32_t)((nodes + 255) / 256);
+  const uint32_t wgrid = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 16 KiB of staged stream each)
   HIP_TRY(hipFuncSetAttribute((const void*)split_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
-  uint32_t h_changed[128];
-  int r = 0;
-  bool converged = false;
-  while (r < kMaxRounds && !converged) {
-    // (a look costs about two rounds: few at first, where text-like streams settle, then further apart)
-    const int step = r < 8 ? 4 : (r < 16 ? 6 : 10);
-    const int r_hi = r + step < kMaxRounds ? r + step : kMaxRounds;
-    for (; r < r_hi; r++) {
-      sp.nxt_in = nxt[r & 1];
-      sp.nxt_out = nxt[(r + 1) & 1];
-      sp.changed = changed;
-      sp.locate = 0;
-      if (r + 1 == r_hi) HIP_TRY(hipMemsetAsync(changed, 0, 128 * 4, s));  // the look reads the last round's words
+  HIP_TRY(hipFuncSetAttribute((const void*)split_locate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
+  const uint32_t root = kSplitTrusted;  // (node 0: position 0, no guess)
+  HIP_TRY(hipMemcpyAsync(ent, &root, 4, hipMemcpyHostToDevice, s));
+  int steps = 1;  // pointer doublings that cover a chain of nseg nodes
+  while ((1ull << steps) < (uint64_t)nseg + 1) steps++;
+  bool done = false;
+  int cur = 0;
+  for (int look = 0; look < kMaxLooks && !done; look++) {
+    for (int r = 0; r < (look == 0 ? kRoundsFirst : kRoundsLater); r++) {
       LaunchTimer lt(c, s, 7);
+      sp.first = look == 0 && r == 0;
       LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
     }
-    // is this the right state already?  (split_check_kernel: a proof that does not depend on the rounds)
-    HIP_TRY(hipMemsetAsync(reached, 0, (size_t)nseg * 4, s));
-    HIP_TRY(hipMemsetAsync(changed + 64, 0, 4, s));
-    LAUNCH(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 0);
-    LAUNCH(split_check_kernel, dim3(grid), dim3(256), 0, s, sp, reached, changed + 64, 1);
+    // is the real chain complete?  mark what the root reaches; its last pointer tells
+    LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach);
+    cur = 0;
+    for (int k = 0; k < steps; k++, cur ^= 1)
+      LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_changed, changed, sizeof h_changed, hipMemcpyDeviceToHost, s));
+    uint32_t h_root = 0, h_cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&h_root, jump[cur], 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_cnt, counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    converged = h_changed[64] == 0;
-    // (streams of long literals back to back -- incompressible data -- settle one literal per round:
-    // past a point the serial walk is the better deal)
-    if (!converged && r >= 31 && h_changed[0] > nseg / 64) r = kMaxRounds;
     if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
-      fprintf(stderr, "SPLIT round %d changed %u check %s\n", r, h_changed[0], converged ? "ok" : "no");
+      fprintf(stderr, "SPLIT look %d: root -> %08x, candidates added %u, overflow %u\n", look, h_root, h_cnt[0], h_cnt[1]);
+    if (h_root == kSplitEnd) done = true;
+    // an invalid or foreign element on the chain (for the serial walk to judge); a list that overflowed
+    // may have dropped the candidate the chain needs: one more look, then the serial walk
+    else if (h_root == kSplitBad || (h_cnt[1] && look >= 1)) return -1;
   }
-  if (!converged) return -1;
+  if (!done) return -1;
+  LAUNCH(split_select_kernel, dim3(grid), dim3(256), 0, s, sp, (const uint8_t*)reach);
   LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108 (or an invalid element cut the walk short)
+  if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108
   (void)nblk;
-  sp.locate = 1;
-  LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
+  LAUNCH(split_locate_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
   HIP_TRY(hipGetLastError());
   uint32_t h_flags[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
@@ -1452,7 +1457,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
 int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32_t hdr, uint64_t len,
                           uint8_t* out, size_t* written, const uint8_t* d_in_res = nullptr,
                           uint8_t* d_out_res = nullptr) {
-  if (len > (1ull << 31) || n > (1ull << 31)) return -1;
+  if (len > (1ull << 31) || n >= (1ull << 31)) return -1;  // (positions carry a flag in bit 31: split_kernels.h)
   int st;
   const size_t nblk = (size_t)((len + kMaxBlockLen - 1) / kMaxBlockLen);
   void *d_in = const_cast<uint8_t*>(d_in_res), *d_out = d_out_res, *d_io, *d_il, *d_oo, *d_oc, *d_ol, *d_st, *d_blk,

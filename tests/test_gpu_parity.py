@@ -382,6 +382,12 @@ def test_random_multi_block_raw_buffers(hip, orc):
     big = [rng.randbytes(6 << 20),
            b"".join(text[:rng.randint(1, 200000)] + rng.randbytes(rng.randint(1, 400000)) for _ in range(12)),
            rng.randbytes(65536 * 3 + 17) + text[:70000] + rng.randbytes(65536 * 20)]
+    # periods: the copies of a period are an element stream of period 3 ("fe 0a 00" ...) that parses as a
+    # chain of copy2 elements from its second byte too -- two chains side by side that never fall into step
+    # (periods 10, 14, 18: the offset's low byte is a copy2 tag); candidates + marking must pick the real one
+    for period in (10, 14, 18, 254, 300):
+        big.append((text[5000:5000 + period] * (400000 // period + 1))[:400000])
+    big.append(b"".join((text[k * 100:k * 100 + 14] * 6000) + text[:30000] for k in range(6)))
     for i, src in enumerate(big):
         comp = orc.encode(src)
         assert hip.decode(comp) == src, i
