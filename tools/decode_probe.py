@@ -10,7 +10,7 @@ classes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["T_TEXT", "T_HTML"]
 dev = torch.device("cuda", 0)
 ctx = hip.Context(0)
 for cls in classes:
-    d_in = corpus.make_blocks_torch(torch, 0, nb, dev, only=cls).reshape(-1)
+    d_in = corpus.make_blocks_torch(torch, 0, nb, dev, only=None if cls == "MIX" else cls).reshape(-1)
     d_slots = torch.empty(nb * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
     d_sizes = torch.empty(nb, dtype=torch.int32, device=dev)
     d_offsets = torch.empty(nb + 1, dtype=torch.int64, device=dev)
@@ -33,7 +33,8 @@ for cls in classes:
             ms, n = ctx.kernel_ms(0)
             ims, _ = ctx.kernel_ms(4)
             ms8, _ = ctx.kernel_ms(8)
+            ms5, _ = ctx.kernel_ms(5)
             ctx.timing(False)
         print(cls, "dbg", dbg, "ms %.3f" % ms, "index ms %.3f" % ims, "per-block us (512 concurrent) %.1f" % (ms * 1e3 * 512 / nb),
-              "C/block %d" % (tot // nb), "second launch ms %.3f" % ms8,
+              "C/block %d" % (tot // nb), "second launch ms %.3f" % ms8, "one-pass ms %.3f" % ms5,
               "ok" if bool((d_out == d_in).all().item()) and int(d_status.abs().sum().item()) == 0 else "WRONG", flush=True)
