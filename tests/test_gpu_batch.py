@@ -78,6 +78,14 @@ def test_corpus_sample_bit_exact(hip, orc, torch_mod):
     assert (d_dec.cpu().numpy() == flat).all()
     crcs = d_crc.cpu().numpy().view(np.uint32)
     assert [int(c) for c in crcs] == [orc.masked_crc(blocks[i].tobytes()) for i in range(nb)]
+    # the same without the CRC buffer: the ring-window instantiation of the indexed decoder goes first
+    d_dec.zero_()
+    d_status.fill_(77)
+    d_out_len.zero_()
+    ctx.decode_blocks(d_out, d_in_off, d_in_len, nb, d_dec, d_out_off, d_out_cap, d_out_len, d_status, unit=hip.UNIT_RAW)
+    ctx.sync()
+    assert (d_status.cpu().numpy() == 0).all() and (d_out_len.cpu().numpy() == 65536).all()
+    assert (d_dec.cpu().numpy() == flat).all()
     ctx.close()
 
 
@@ -466,6 +474,15 @@ def test_launch_order_large_batch(hip, orc, torch_mod):
             assert int(crcs[i]) == orc.masked_crc(expect[i]), i
         results.append((out.copy(), crcs.copy()))
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    # and without the CRC buffer (ring-window instantiation first, the whole-block one for what it passes on)
+    d_out = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+    d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+    ctx.decode_blocks(d_stream, _dev(torch, in_off), _dev(torch, in_len), nb, d_out, _dev(torch, out_off),
+                      _dev(torch, cap), d_out_len, d_status, unit=hip.UNIT_RAW)
+    ctx.sync()
+    assert (d_status.cpu().numpy() == 0).all()
+    assert np.array_equal(d_out.cpu().numpy(), results[0][0])
     ctx.close()
 
 
