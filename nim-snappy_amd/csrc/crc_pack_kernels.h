@@ -217,10 +217,28 @@ __global__ __launch_bounds__(64) void order_scan_kernel(uint32_t* counts) {
   counts[2 * lane + 1] = before + a;
 }
 
+// (a workgroup ranks its 256 items per bucket in LDS and reserves each bucket's range with ONE atomic on the
+// global cursor: item by item, 65 536 returning atomics on 128 hot words took 0.15 ms)
 __global__ __launch_bounds__(256) void order_scatter_kernel(const uint32_t* keys, uint64_t n, int mode, uint32_t* cursor,
                                                             uint32_t* perm) {
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    perm[atomicAdd(&cursor[order_bucket(keys[i], mode)], 1u)] = (uint32_t)i;
+  __shared__ uint32_t s_c[kOrderBuckets], s_base[kOrderBuckets];
+  static_assert(kOrderBuckets <= 256, "one thread per bucket");
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x; i0 < n; i0 += stride) {  // (uniform trip count)
+    if (threadIdx.x < kOrderBuckets) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = i0 + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (i < n) {
+      b = order_bucket(keys[i], mode);
+      rank = atomicAdd(&s_c[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kOrderBuckets && s_c[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_c[threadIdx.x]);
+    __syncthreads();
+    if (i < n) perm[s_base[b] + rank] = (uint32_t)i;
+    __syncthreads();
+  }
 }
 
 // The encoder's blocks have no length to go by, so blocks that look alike are put next to each
