@@ -156,9 +156,12 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // one block's chain behind the others': profiles/README.md).  Every step starts by writing the bytes that
 // became final one step ago to HBM; a copy whose source is older than what this step leaves of the ring
 // (ring_lo) reads it back from there -- those bytes were written at least a step earlier (far_lo, with a
-// wait for the stores in front of the barrier in between).  The ring is sound while the output of the step being parsed, the step
-// being resolved and the one before it fit in WIN bytes (checked per step); a unit where they do not is
-// handed to the whole-block instantiation (kNeedsWindow), launched second over the same units.
+// wait for the stores in front of the barrier in between).  The ring is sound while the output of the step
+// being parsed, the step being resolved and the one before it fit in WIN bytes; where they do not (a "wide"
+// step: much output from little stream) everything final is written and waited for at once, after which two
+// steps must fit.  A unit with a step wider than that, with more than kRingCatchUps wide steps, or with an
+// output that is not 16-byte aligned is handed to the whole-block instantiation (kNeedsWindow), launched
+// second over the same units.
 template <uint32_t WIN>
 __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       }
     }
   }
-  // ---- ring window: is the unit one for it? (three consecutive steps' output must fit, see above) ----
+  // ---- ring window: is the unit one for it? (see above) ----
   uint32_t flushed = 0;  // (ring) every output byte below this has been written to HBM ...
   uint32_t far_lo = 0;   // ... and below this, a step earlier: visible to the whole workgroup
   uint32_t ring_lo = 0;  // what this step leaves of the ring: positions from here on (<= far_lo)
