@@ -1476,7 +1476,10 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   if (!d_in_res) HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
   // first the speculative parallel walk (split_kernels.h); the one-workgroup walk below is its fallback
-  const int spec = dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT")
+  // (a look at the chain is ~20 small launches and a synchronisation, ~0.4 ms before anything is decoded: below
+  // ~200 KiB of stream the one-workgroup walk, 1 GB/s, is there first)
+  constexpr size_t kSpecMinStream = 192 << 10;
+  const int spec = (dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT") || n - hdr < kSpecMinStream)
                        ? -1
                        : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk, s);
   if (spec > 0) return spec;
