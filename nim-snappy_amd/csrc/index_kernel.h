@@ -311,7 +311,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         // bytes) exit at nx itself, with their own length and a size that fits a byte
         uint32_t nx = (uint32_t)k + size;
         uint32_t out_code = nx, Ls = L, szb = size;
-        if (ballot(inside && (e >> 14))) {  // a literal with length bytes somewhere (rare in text)
+        if (__builtin_expect(ballot(inside && (e >> 14)) != 0, 0)) {  // a literal with length bytes somewhere (rare in text)
           const uint32_t rem = inside ? n - p - 1 : 0;
           const uint32_t lenlen = (tag >> 2) - 59;  // 1..4 where it applies
           const uint32_t m = 0xffffffffu >> (32 - 8 * (lenlen & 7 ? (lenlen & 7) : 4));
