@@ -1432,7 +1432,14 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   }
   if (!done) return -1;
   LAUNCH(split_select_kernel, dim3(grid), dim3(256), 0, s, sp, (const uint8_t*)reach);
-  LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, outb, (uint64_t)nseg, (uint64_t)0, out_at);
+  {  // out_at = exclusive prefix sum of outb (tile sums live in the jump tables, which are free now)
+    const uint32_t tiles = (nseg + kSplitTile - 1) / kSplitTile;
+    uint32_t* tile_sum = jump[0];
+    uint64_t* tile_base = (uint64_t*)jump[1];  // [tiles + 1] (nodes * 4 bytes >= that)
+    LAUNCH(split_tile_sums_kernel, dim3(tiles), dim3(256), 0, s, (const uint32_t*)outb, nseg, tile_sum);
+    LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, (const uint32_t*)tile_sum, (uint64_t)tiles, (uint64_t)0, tile_base);
+    LAUNCH(split_tile_scan_kernel, dim3(tiles), dim3(256), 0, s, (const uint32_t*)outb, nseg, (const uint64_t*)tile_base, out_at);
+  }
   uint64_t total = 0;
   HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

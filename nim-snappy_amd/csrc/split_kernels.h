@@ -231,6 +231,48 @@ __global__ __launch_bounds__(256) void split_select_kernel(SplitParams p, const 
   p.outb[s] = o;
 }
 
+// Exclusive prefix sum of outb over millions of segments (one workgroup running through them takes 3 ms for a
+// GiB of stream): tiles of 4096 are summed, the few hundred tile sums are scanned by scan_sizes_kernel, and
+// every tile is scanned again from its base.
+constexpr uint32_t kSplitTile = 4096;
+__global__ __launch_bounds__(256) void split_tile_sums_kernel(const uint32_t* v, uint32_t n, uint32_t* tile_sum) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t lo = blockIdx.x * kSplitTile;
+  uint32_t x = 0;
+  for (uint32_t i = lo + threadIdx.x; i < lo + kSplitTile && i < n; i += 256) x += v[i];
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];  // (a tile's output: < 2^32)
+}
+__global__ __launch_bounds__(256) void split_tile_scan_kernel(const uint32_t* v, uint32_t n, const uint64_t* tile_base,
+                                                               uint64_t* offsets) {
+  __shared__ uint64_t s_w[4];
+  __shared__ uint64_t s_carry;
+  const uint32_t lo = blockIdx.x * kSplitTile, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_carry = tile_base[blockIdx.x];
+    if (blockIdx.x == 0) offsets[0] = 0;
+  }
+  __syncthreads();
+  for (uint32_t c = lo; c < lo + kSplitTile; c += 256) {
+    const uint32_t i = c + threadIdx.x;
+    uint64_t x = i < n ? v[i] : 0;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint64_t before = s_carry;
+    for (uint32_t k = 0; k < wv; k++) before += s_w[k];
+    if (i < n) offsets[i + 1] = before + x;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = before + x;
+    __syncthreads();
+  }
+}
+
 // the last walk, along the real chain: which element starts at each 64 KiB boundary of the output
 __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
   const uint32_t s = blockIdx.x * kSplitWg + threadIdx.x;

@@ -11,6 +11,16 @@ lib = hip.lib
 nb = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16384   # 1 GiB
 src = np.ascontiguousarray(corpus.make_blocks(0, nb).reshape(-1))
 n = src.size
+PINNED = "--pinned" in sys.argv  # the caller's buffers are page-locked (hipHostMalloc via torch)
+if PINNED:
+    import torch
+    _keep = []
+    def empty(k):
+        t = torch.empty(k, dtype=torch.uint8).pin_memory(); _keep.append(t)
+        return t.numpy()
+    p = empty(n); p[:] = src; src = p
+else:
+    empty = lambda k: np.empty(k, dtype=np.uint8)
 P = lambda a: ctypes.c_void_p(a.ctypes.data)
 def best(f, reps=3):
     f()
@@ -19,19 +29,19 @@ def best(f, reps=3):
         t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
     return min(ts), r
 cap = hip.max_compressed_len_framed(n)
-fr = np.empty(cap, dtype=np.uint8); w = ctypes.c_size_t(); r = ctypes.c_size_t()
+fr = empty(cap); w = ctypes.c_size_t(); r = ctypes.c_size_t()
 def cf(inp=src, out=fr, ww=w):
     st = lib.snappy_hip_compress_framed(ctypes.cast(P(inp), ctypes.c_char_p), inp.size, P(out), out.size, ctypes.byref(ww)); assert st == 0, st
     return ww.value
 res = {}
 t, flen = best(cf); res["host_compress_framed_GBps"] = n / t / 1e9
-back = np.empty(n, dtype=np.uint8)
+back = empty(n)
 def uf():
     st = lib.snappy_hip_uncompress_framed(ctypes.cast(P(fr), ctypes.c_char_p), flen, P(back), n, 1, 1, ctypes.byref(r), ctypes.byref(w)); assert st == 0, st
 t, _ = best(uf); res["host_uncompress_framed_GBps"] = n / t / 1e9
 assert r.value == flen and w.value == n and np.array_equal(back, src)
 if n < 2**32:
-    raw = np.empty(hip.max_compressed_len(n), dtype=np.uint8)
+    raw = empty(hip.max_compressed_len(n))
     def cr():
         st = lib.snappy_hip_compress(ctypes.cast(P(src), ctypes.c_char_p), n, P(raw), raw.size, ctypes.byref(w)); assert st == 0, st
         return w.value
@@ -43,7 +53,7 @@ if n < 2**32:
     assert w.value == n and np.array_equal(back, src)
 # two host threads, each its own half, each with its own output
 half = n // 2
-outs = [np.empty(cap, dtype=np.uint8) for _ in range(2)]
+outs = [empty(cap) for _ in range(2)]
 ws = [ctypes.c_size_t(), ctypes.c_size_t()]
 def work(i):
     cf(src[i * half:(i + 1) * half], outs[i], ws[i])
