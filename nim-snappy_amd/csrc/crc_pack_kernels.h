@@ -82,26 +82,35 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
     const uint32_t rows = (n + row_bytes - 1) / row_bytes;
     const int64_t pad = (int64_t)rows * row_bytes - n;  // virtual leading zero bytes
     uint32_t s = 0;
-    for (uint32_t r = 0; r < rows; r++) {
+    auto word = [&](uint32_t r) -> uint32_t {  // my dword of row r
       const int64_t pos = (int64_t)r * row_bytes + 4 * t - pad;
-      uint32_t w;
-      if (pos >= 4) {
-        w = ld32u(msg + pos);
-      } else {  // touches the message start: virtual zero padding and the 0xffffffff init
-        w = 0;
-        for (int k = 0; k < 4; k++) {
-          const int64_t j = pos + k;
-          if (j >= 0) w |= (uint32_t)(msg[j] ^ (j < 4 ? 0xff : 0)) << (8 * k);
-        }
+      if (pos >= 4) return ld32u(msg + pos);
+      uint32_t w = 0;  // touches the message start: virtual zero padding and the 0xffffffff init
+      for (int k = 0; k < 4; k++) {
+        const int64_t j = pos + k;
+        if (j >= 0) w |= (uint32_t)(msg[j] ^ (j < 4 ? 0xff : 0)) << (8 * k);
       }
+      return w;
+    };
+    auto step = [&](uint32_t r, uint32_t w) {
       const uint32_t x = s ^ w;
       if (r + 1 < rows) {
-        s = s_tab[0][x & 0xff] ^ s_tab[1][(x >> 8) & 0xff] ^ s_tab[2][(x >> 16) & 0xff] ^
-            s_tab[3][x >> 24];
+        s = s_tab[0][x & 0xff] ^ s_tab[1][(x >> 8) & 0xff] ^ s_tab[2][(x >> 16) & 0xff] ^ s_tab[3][x >> 24];
       } else {
         s = gf2_mulmod(prm.col_mul[t], x);  // the 4*(256-t) bytes from here to the end
       }
+    };
+    // (the rows' loads do not depend on the register: four go out together, the chain of table lookups
+    // behind them -- a row at a time, each waiting for its own load, is bound by the trip to memory)
+    uint32_t r = 0;
+    for (; r + 4 <= rows; r += 4) {
+      const uint32_t w0 = word(r), w1 = word(r + 1), w2 = word(r + 2), w3 = word(r + 3);
+      step(r, w0);
+      step(r + 1, w1);
+      step(r + 2, w2);
+      step(r + 3, w3);
     }
+    for (; r < rows; r++) step(r, word(r));
     for (int d = 32; d >= 1; d >>= 1) s ^= __shfl_xor(s, d, 64);
     if ((t & 63) == 0) s_part[t >> 6] = s;
     __syncthreads();
