@@ -1403,8 +1403,8 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   HIP_TRY(hipFuncSetAttribute((const void*)split_locate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   const uint32_t root = kSplitTrusted;  // (node 0: position 0, no guess)
   HIP_TRY(hipMemcpyAsync(ent, &root, 4, hipMemcpyHostToDevice, s));
-  int steps = 1;  // pointer doublings that cover a chain of nseg nodes
-  while ((1ull << steps) < (uint64_t)nseg + 1) steps++;
+  int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
+  while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
   bool done = false;
   int cur = 0;
   for (int look = 0; look < kMaxLooks && !done; look++) {

@@ -121,16 +121,19 @@ def split(s, max_looks=10):
         reach = [False] * len(keys)
         reach[0] = True
         steps = 1
-        while (1 << steps) < nseg + 1:
+        while (1 << (2 * steps)) < nseg + 1:
             steps += 1
-        for _ in range(steps):
+        for _ in range(steps):  # four-fold jumps: a marked node marks 1, 2 and 3 hops of the current pointers
             nj = list(jump)
             for i, j in enumerate(jump):
-                if j < 0:
-                    continue
-                if reach[i]:
-                    reach[j] = True
-                nj[i] = jump[j]
+                mark = j >= 0 and reach[i]
+                for _hop in range(3):
+                    if j < 0:
+                        break
+                    if mark:
+                        reach[j] = True
+                    j = jump[j]
+                nj[i] = j
             jump = nj
         if jump[0] == END:
             return {t: ent[t][c] for (t, c), i in ids.items() if reach[i]}, rounds
