@@ -1353,7 +1353,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
                       uint32_t* d_blk, hipStream_t s) {
   // rounds before the first look at the chain (text-like data is complete by then), between later looks
   // (a handful of late candidates), looks before the serial walk takes over
-  constexpr int kRoundsFirst = 4, kRoundsLater = 2, kMaxLooks = 10;
+  constexpr int kRoundsFirst = 4, kRoundsLater = 4, kMaxLooks = 6;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
   const size_t nodes = (size_t)nseg * kSplitCand;
   void* base;
