@@ -34,7 +34,7 @@ def test_marked_chain_is_the_sequential_parse(orc):
         got = sm.split(s)
         assert want is not None and got is not None, i
         assert got[0] == want, (i, got[1])
-        assert got[1] <= 16, (i, got[1])  # rounds: the first look, or a few more
+        assert got[1] <= 16, (i, got[1])  # rounds: the first look, or a few more (a look every four rounds)
 
 
 def test_a_damaged_stream_is_refused_or_right(orc):

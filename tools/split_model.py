@@ -38,7 +38,7 @@ def native(tag):
     return not ((tag & 3) == 3 or ((tag & 3) == 0 and (tag >> 2) >= 62))
 
 
-def split(s, max_looks=10):
+def split(s, max_looks=6):
     """-> (entries {segment: entry position} of the marked chain, rounds) or None (the kernels would fall back)"""
     n = len(s)
     nseg = (n + SEG - 1) // SEG
@@ -93,7 +93,7 @@ def split(s, max_looks=10):
 
     rounds = 0
     for look in range(max_looks):
-        for r in range(4 if look == 0 else 2):
+        for r in range(4):
             todo = [(t, c) for t in range(nseg) for c in range(len(ent[t])) if ext[t][c] == PENDING]
             results = []
             if look == 0 and r == 0:
