@@ -1523,40 +1523,34 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
             h[1] / nch, h[2] / nch);
     (void)hipFree(d_sdbg);
   }
-  std::vector<uint32_t> blk(nblk + 1);
-  HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(blk.data(), d_blk, (nblk + 1) * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (spec < 0) {
+  if (spec < 0) {  // the one-workgroup walk's verdict (the speculative walk has given its own)
+    HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
     if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
   }
-  blk[0] = 0;
-  blk[nblk] = (uint32_t)(n - hdr);
-  std::vector<uint64_t> io(nblk), oo(nblk);
-  std::vector<uint32_t> il(nblk), oc(nblk);
-  for (size_t k = 0; k < nblk; k++) {
-    if (blk[k] == 0xffffffffu || blk[k + 1] == 0xffffffffu || blk[k + 1] < blk[k]) return -1;
-    io[k] = hdr + (uint64_t)blk[k];
-    il[k] = blk[k + 1] - blk[k];
-    oo[k] = (uint64_t)k * kMaxBlockLen;
-    oc[k] = (uint32_t)(len - oo[k] < kMaxBlockLen ? len - oo[k] : kMaxBlockLen);
-  }
-  HIP_TRY(hipMemcpyAsync(d_io, io.data(), nblk * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_il, il.data(), nblk * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_oo, oo.data(), nblk * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_oc, oc.data(), nblk * 4, hipMemcpyHostToDevice, s));
+  // the blocks as units, on the device (no trip to the host in between); d_one[6]: a block without a start
+  uint32_t* d_bad = (uint32_t*)d_one + 6;
+  HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
+  LAUNCH(split_table_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_blk, (uint32_t)nblk,
+         (uint32_t)(n - hdr), hdr, len, (uint64_t*)d_io, (uint32_t*)d_il, (uint64_t*)d_oo, (uint32_t*)d_oc, d_bad);
   HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
   if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nblk,
                      (int)kUnitBody, nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
                      (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
     return st;
   std::vector<uint32_t> stv(nblk), olv(nblk);
+  uint32_t h_bad = 0;
   HIP_TRY(hipMemcpyAsync(stv.data(), d_st, nblk * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(olv.data(), d_ol, nblk * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  for (size_t k = 0; k < nblk; k++)
-    if (stv[k] != kOk || olv[k] != oc[k]) return -1;  // e.g. a copy that reaches into an earlier block
+  if (h_bad) return -1;
+  for (size_t k = 0; k < nblk; k++) {
+    const uint64_t oo = (uint64_t)k * kMaxBlockLen;
+    const uint32_t oc = (uint32_t)(len - oo < kMaxBlockLen ? len - oo : kMaxBlockLen);
+    if (stv[k] != kOk || olv[k] != oc) return -1;  // e.g. a copy that reaches into an earlier block
+  }
   if (!d_out_res) HIP_TRY(hipMemcpy(out, d_out, len, hipMemcpyDeviceToHost));
   *written = (size_t)len;
   return SNAPPY_HIP_OK;

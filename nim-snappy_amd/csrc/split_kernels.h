@@ -301,4 +301,20 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
   }
 }
 
+// the blocks as units of the block decoder, from where they start in the stream (blk_in[k], k >= 1; block 0 at 0)
+__global__ __launch_bounds__(256) void split_table_kernel(const uint32_t* blk_in, uint32_t nblk, uint32_t n_tags,
+                                                          uint32_t hdr, uint64_t len, uint64_t* in_off, uint32_t* in_len,
+                                                          uint64_t* out_off, uint32_t* out_cap, uint32_t* bad) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nblk) return;
+  const uint32_t b0 = k == 0 ? 0 : blk_in[k], b1 = k + 1 == nblk ? n_tags : blk_in[k + 1];
+  const bool ok = b0 != 0xffffffffu && b1 != 0xffffffffu && b1 >= b0 && b1 <= n_tags;
+  if (!ok) *bad = 1;  // (a block nobody recorded the start of: the caller falls back; the unit is made empty)
+  const uint64_t oo = (uint64_t)k * kMaxBlockLen;
+  in_off[k] = (uint64_t)hdr + (ok ? b0 : 0);
+  in_len[k] = ok ? b1 - b0 : 0;
+  out_off[k] = oo;
+  out_cap[k] = (uint32_t)(len - oo < kMaxBlockLen ? len - oo : kMaxBlockLen);
+}
+
 }  // namespace snappy_hip
