@@ -76,6 +76,7 @@ struct Decode2Params {
   uint64_t n_units;
   int unit;
   int second;  // the launch after the ring-window one: only the units that one passed on (kNeedsWindow)
+  const uint32_t* pass_list;  // ... listed by passed_on_list_kernel; pass_list[-2] = how many
   int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
   unsigned long long* stats;  // DEBUG counters (nullptr = off)
   // masked CRC32C of every unit's output, computed from the LDS window while it is flushed
@@ -188,7 +189,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   const uint32_t lane = tid & 63;
   const uint32_t wave = readfirst(tid >> 6);  // (scalar register: wave-uniform by construction)
   if (blockIdx.x >= prm.n_units) return;
-  const uint64_t u = prm.order ? prm.order[blockIdx.x] : blockIdx.x;  // (launch order, crc_pack_kernels.h)
+  // (the launch behind the ring-window one: workgroup i takes the i-th unit on the list of passed-on units --
+  // a workgroup with nothing to do leaves after one load, not after a chain of two)
+  if (!RING && prm.second && blockIdx.x >= prm.pass_list[-2]) return;
+  const uint64_t u = (!RING && prm.second) ? prm.pass_list[blockIdx.x]
+                                           : (prm.order ? prm.order[blockIdx.x] : blockIdx.x);  // (launch order, crc_pack_kernels.h)
   // The start of a workgroup is a chain of dependent trips to HBM (which unit -> its parameters ->
   // its first bytes -> its index and stream), and a block's latency is what this kernel is bound by:
   // everything that can go out together does.  First every per-unit parameter ...
@@ -1020,6 +1025,22 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       prm.crc_done[u] = 1;
     }
   }
+}
+
+// The units the ring-window launch passed on (status kNeedsWindow), in launch order (wave by wave): list[-2] =
+// how many.  One thread per unit.
+__global__ __launch_bounds__(256) void passed_on_list_kernel(const uint32_t* status, const uint32_t* order, uint64_t n_units,
+                                                             uint32_t* list) {
+  const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+  const uint32_t u = i < n_units ? (order ? order[i] : (uint32_t)i) : 0;
+  const bool mine = i < n_units && status[u] == kNeedsWindow;
+  const uint64_t m = ballot(mine);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(list - 2, (uint32_t)__builtin_popcountll(m));
+  base = readfirst(base);
+  if (mine) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = u;
 }
 
 // Region count per unit for the index (bounded: the index pass stops once a unit has produced

@@ -118,7 +118,7 @@ struct snappy_hip_ctx {
   uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
-  DevBuf ws[20];                   // grow-only workspace of the host-buffer API
+  DevBuf ws[24];                   // grow-only workspace of the host-buffer API
   bool timing = false;
   struct Timed {
     hipEvent_t a, b;
@@ -589,6 +589,14 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     if (ring_first) {
       LaunchTimer lt(c, s, 0);
       LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), out_alloc(kRingWin), s, dp);
+    }
+    if (ring_first) {  // the units it passed on, as a list
+      void* d_pass;
+      if ((st = ws_get(c, 20, 8 + n_units * 4, &d_pass))) return st;
+      HIP_TRY(hipMemsetAsync(d_pass, 0, 8, s));
+      dp.pass_list = (const uint32_t*)d_pass + 2;
+      LAUNCH(passed_on_list_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_status,
+             dp.order, n_units, (uint32_t*)d_pass + 2);
     }
     {
       LaunchTimer lt(c, s, ring_first ? 8 : 0);
