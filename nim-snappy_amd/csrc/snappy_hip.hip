@@ -1356,7 +1356,8 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // Block starts of one raw buffer by the speculative parallel walk of split_kernels.h.  d_tags = the
 // tag stream (behind the varint) in device memory.  Returns 0 (d_blk[k] = stream position of block
 // k's first element for every k), a status > 0 (the walk saw the whole stream: its verdict stands), or
-// -1: not applicable (no fixed point within the round limit, an element straddles a block boundary).
+// -1: not applicable (the chain is not complete within the looks, an invalid or foreign element lies on it, a
+// candidate list overflowed, an element straddles a block boundary).
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s) {
   // rounds before the first look at the chain (text-like data is complete by then), between later looks
