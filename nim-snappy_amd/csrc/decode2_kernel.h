@@ -60,6 +60,7 @@ constexpr bool kD2RingFirst = D2_RING != 0;
 constexpr uint32_t kRingCatchUps = D2_RING_CATCHUPS;  // wide steps (see the kernel) a unit may have in the ring
 // dynamic LDS of a launch: the window and 64 scratch dwords behind it, one per lane (no bank conflicts)
 constexpr uint32_t out_alloc(uint32_t win) { return win + 256; }
+constexpr uint32_t kD2DynWindow = out_alloc(kMaxBlockLen);  // dynamic LDS of the whole-block instantiation's launches
 constexpr uint32_t kMaxSteps = kMaxFastIn / kChunk + 2;
 
 struct Decode2Params {
@@ -145,7 +146,7 @@ __device__ __attribute__((noinline)) void extend_run(lds_u8* out, uint32_t g, ui
   }
 }
 
-// The output window is DYNAMIC shared memory (launch with out_alloc(WIN) bytes): with the whole
+// The whole-block output window is DYNAMIC shared memory (launch with kD2DynWindow bytes): with the whole
 // footprint declared statically the compiler derives "at most N waves per SIMD" from it and pads
 // the kernel's VGPR allocation to enforce that -- which can leave no room for the second
 // workgroup of a CU (measured: one workgroup per CU with 5 waves per workgroup).
@@ -168,7 +169,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   constexpr bool RING = WIN < kMaxBlockLen;
   constexpr uint32_t kOutSink = WIN;
   auto wa = [](uint32_t x) -> uint32_t { return RING ? (x & (WIN - 1)) : x; };  // window address of output byte x
-  uint8_t* const s_out = s_dyn_window;
+  // (the ring window is a static array: its LDS address is then a compile-time constant that folds into the
+  // instructions' offset fields -- the dynamic array's base is added to every address with an instruction;
+  // -2.5 % kernel time)
+  __shared__ __attribute__((aligned(16))) uint8_t s_static_window[RING ? out_alloc(kRingWin) : 16];
+  uint8_t* const s_out = RING ? s_static_window : s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave
   __shared__ __attribute__((aligned(16))) uint16_t s_r16[kD2Pool][kGroup];

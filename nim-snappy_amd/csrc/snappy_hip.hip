@@ -233,8 +233,6 @@ int ctx_init(snappy_hip_ctx* c) {
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
-  HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kRingWin>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kRingWin) + 8192));
   std::vector<uint32_t> tab(1024), mul(kCrcThreads), so(kSeqLen), ss(kSeqLen);
   build_crc_tables(tab.data(), mul.data());
   {
@@ -588,7 +586,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     const bool ring_first = kD2RingFirst && dp.crc == nullptr && !dbg_env("SNAPPY_HIP_NO_RING");
     if (ring_first) {
       LaunchTimer lt(c, s, 0);
-      LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), out_alloc(kRingWin), s, dp);
+            LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
     }
     if (ring_first) {  // the units it passed on, as a list
       void* d_pass;
@@ -602,7 +600,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       LaunchTimer lt(c, s, ring_first ? 8 : 0);
       dp.second = ring_first ? 1 : 0;
       LAUNCH(decode_indexed_kernel<kMaxBlockLen>, dim3((uint32_t)n_units), dim3(kD2Threads),
-             out_alloc(kMaxBlockLen) + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
+             kD2DynWindow + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
     }
     if (d_stats) {
       unsigned long long h[16];
