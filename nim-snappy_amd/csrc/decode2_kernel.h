@@ -334,21 +334,44 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
     const uint32_t sh8 = sh * 8;
     uint32_t s0 = rd(0u), s1 = rd(1u), s2 = rd(2u);
     uint32_t v0 = __funnelshift_r(s0, s1, sh8), v1 = __funnelshift_r(s1, s2, sh8);
+    // A byte's address is (it is mine ? the element's window address : my sink) + j: one select per byte, and
+    // the + j rides in the store's offset field.  (An element that runs over the ring's end -- one in a few
+    // thousand -- takes the form with a wrap per byte.)
+    const uint32_t b0 = wa(dst);
+    if (RING && __builtin_expect(ballot(L != 0 && b0 + L > WIN) != 0, 0)) {
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[L > j ? wa(dst + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
+      for (uint32_t j = 0; j < 4; j++) s_out[L > j ? wa(dst + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? wa(dst + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
+      for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? wa(dst + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
+      for (uint32_t k = 8; ballot(L > k); k += 8) {
+        s0 = s2;
+        s1 = rd(k / 4 + 1);
+        s2 = rd(k / 4 + 2);
+        v0 = __funnelshift_r(s0, s1, sh8);
+        v1 = __funnelshift_r(s1, s2, sh8);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? wa(dst + k + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+          s_out[L > k + 4 + j ? wa(dst + k + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
+      }
+      return;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) s_out[(L > j ? b0 : sink) + j] = (uint8_t)(v0 >> (8 * j));
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) s_out[(L > 4 + j ? b0 : sink - 4) + 4 + j] = (uint8_t)(v1 >> (8 * j));
     for (uint32_t k = 8; ballot(L > k); k += 8) {  // longer elements: 8 more bytes per trip
       s0 = s2;
       s1 = rd(k / 4 + 1);
       s2 = rd(k / 4 + 2);
       v0 = __funnelshift_r(s0, s1, sh8);
       v1 = __funnelshift_r(s1, s2, sh8);
+      const uint32_t bk = b0 + k;
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? wa(dst + k + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
+      for (uint32_t j = 0; j < 4; j++) s_out[(L > k + j ? bk : sink) + j] = (uint8_t)(v0 >> (8 * j));
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++)
-        s_out[L > k + 4 + j ? wa(dst + k + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
+      for (uint32_t j = 0; j < 4; j++) s_out[(L > k + 4 + j ? bk : sink - 4) + 4 + j] = (uint8_t)(v1 >> (8 * j));
     }
   };
   auto ring_al = [&](uint32_t q) -> uint32_t {  // aligned dword that holds stream byte q - shift
