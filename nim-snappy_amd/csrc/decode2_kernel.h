@@ -547,13 +547,18 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         if (pq[i] < q_end) ring_store(pq[i], pre[i]);
     }
     // next step's index entries and the 2 KiB of stream after the ring's contents
-    ie_pref = idx_at((s + 1) * 128 + half * 64 + lane);
-    io_pref = idx_at((s + 1) * 128 + (1 - half) * 64 + lane);
+    // (the front-end waves only: the resolvers have no use for them)
+    if (fe) {
+      ie_pref = idx_at((s + 1) * 128 + half * 64 + lane);
+      io_pref = idx_at((s + 1) * 128 + (1 - half) * 64 + lane);
+      if (wave == 1) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      pq[i] = s * kChunk + kD2Ring + (lane + 64 * i) * 16;
-      const uint32_t qc = pq[i] < q_end ? pq[i] : 0;  // clamped: always a valid address
-      pre[i] = *reinterpret_cast<const uint4*>(g0 + qc);
+        for (int i = 0; i < 2; i++) {
+          pq[i] = s * kChunk + kD2Ring + (lane + 64 * i) * 16;
+          const uint32_t qc = pq[i] < q_end ? pq[i] : 0;  // clamped: always a valid address
+          pre[i] = *reinterpret_cast<const uint4*>(g0 + qc);
+        }
+      }
     }
 
     if (fe && s < n_chunks) {
