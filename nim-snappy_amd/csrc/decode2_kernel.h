@@ -178,8 +178,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   // pointer-doubling / start-mask scratch, one per resolver wave
   __shared__ __attribute__((aligned(16))) uint16_t s_r16[kD2Pool][kGroup];
   // element lists of the current and the previous step, in stream order
-  __shared__ __attribute__((aligned(4))) uint16_t s_off[2][kElemCap];  // copy offset, 0 = literal
-  __shared__ __attribute__((aligned(4))) uint16_t s_dst[2][kElemCap];  // first output byte
+  // (one dword per element: low half the copy offset, 0 = literal; high half its first output byte -- the
+  // front end writes an entry with one store)
+  __shared__ __attribute__((aligned(4))) uint32_t s_el[2][kElemCap];
   __shared__ uint32_t s_sbase[kMaxSteps];   // output position where step k starts
   __shared__ uint32_t s_cnt[2];             // elements in the list
   __shared__ uint32_t s_front;              // every output byte below this position is final
@@ -579,8 +580,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       if (half) slot += otot;  // the first half's elements come first in the list
       ctot += otot;            // elements of the whole step (<= kElemCap by the format)
       if (wave == 0 && lane == 0) s_cnt[buf] = ctot;
-      uint16_t* const o16 = s_off[buf];
-      uint16_t* const d16 = s_dst[buf];
+      uint32_t* const el = s_el[buf];
 
       const uint32_t rs = c0 + lane * kSub;
       const uint32_t r_end = rs + kSub < n ? rs + kSub : n;
@@ -614,8 +614,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         bad = bad || bad_off;
         // ---- the element's list entry, and its slot at the 256-byte boundary it covers (if any) --
         const bool put = live && slot < kElemCap;
-        *(put ? o16 + slot : sink16) = (cpy && !bad_off) ? (uint16_t)off : (uint16_t)0;
-        *(put ? d16 + slot : sink16 + 1) = (uint16_t)dst;
+        *(put ? el + slot : reinterpret_cast<uint32_t*>(sink16)) = ((cpy && !bad_off) ? (off & 0xffffu) : 0u) | (dst << 16);
         const uint32_t mb = (dst + kGroup - 1) / kGroup;
         const bool covers = live && mb * kGroup < dst + L;
         *(covers ? s_gidx + (mb & (kMaxBlockLen / kGroup - 1)) : sink16) = (uint16_t)slot;
@@ -683,8 +682,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       const uint32_t buf = (s - 1) & 1;
       const uint32_t cb = readfirst(s_sbase[s - 1]), cn = readfirst(s_sbase[s]);
       const uint32_t count = readfirst(s_cnt[buf]);
-      const uint16_t* const o16 = s_off[buf];
-      const uint16_t* const d16 = s_dst[buf];
+      const uint16_t* const el16 = reinterpret_cast<const uint16_t*>(s_el[buf]);
+      auto o16 = [&](uint32_t e) -> uint32_t { return el16[2 * e]; };      // copy offset, 0 = literal
+      auto d16 = [&](uint32_t e) -> uint32_t { return el16[2 * e + 1]; };  // first output byte
       uint16_t* const r16 = s_r16[wave - 2];
       const uint32_t gfirst = cb & ~(kGroup - 1);
       // a group in the middle of one long literal holds no copy (the front end flags the
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         for (uint32_t k = 0; k < B / 2; k++) r32[k] = 0;
         cbar();
         for (uint32_t e = E0 + 1 + lane;; e += 64) {
-          const uint32_t d = e < count ? (uint32_t)d16[e] : 0xffffffffu;
+          const uint32_t d = e < count ? d16(e) : 0xffffffffu;
           const bool in = d - g < kGroup;  // (d > g: the list is in output order)
           r16[in ? d - g : 0] = (uint16_t)(e - E0);
           if (ballot(in) != ~0ull) break;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         for (uint32_t j = 0; j < B; j++) {
           const bool in = (rmask >> j) & 1;
           const uint32_t ei = E0 + (li[j] > before ? li[j] : before);
-          const uint32_t off = o16[in ? ei : 0];
+          const uint32_t off = o16(in ? ei : 0);
           cp[j] = in && off != 0;
           offj[j] = cp[j] ? off : 0;
           sp[j] = p + j - offj[j];
@@ -773,11 +773,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
           if (ballot(off_differs) == 0) {
             uint32_t R = cn;
             for (uint32_t e = E0 + tot + 1 + lane;; e += 64) {  // elements after those of my group
-              const uint32_t oo = e < count ? (uint32_t)o16[e] : 0;
+              const uint32_t oo = e < count ? o16(e) : 0;
               const uint64_t mm = ballot(oo != run_off);
               if (mm) {
                 const uint32_t ef = readfirst(e) + ctz64(mm);
-                if (ef < count) R = readfirst((uint32_t)d16[ef]);
+                if (ef < count) R = readfirst(d16(ef));
                 break;
               }
             }
