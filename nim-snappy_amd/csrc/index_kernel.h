@@ -219,7 +219,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   if (!SPLIT && n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // (SPLIT: the host bounds n and the length)
   bool straddle = false;  // SPLIT: an element crosses a 64 KiB output boundary
 
-  __shared__ uint8_t s_sz[W * 64 * kSizeStride];  // stream size of the element at each position
+  // stream size of the element at each position.  (The block decoder's index walks positions 0..15 only -- to the
+  // first element at or behind byte 16 -- and keeps those 16 sizes in four registers: the pass is bound by how
+  // many waves fit a CU, and without this table a wave needs 8.75 KiB of LDS: 18 waves instead of 14.)
+  __shared__ uint8_t s_sz[SPLIT ? W * 64 * kSizeStride : 16];
 
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
   const uint8_t* g0 = in0 - shift;                // 16-byte aligned
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   uint32_t op = 0;         // output bytes before it (uniform)
   bool ended = false;
   const uint32_t row = (wave * 64 + lane) * kRowStride;
-  const uint32_t row8 = (wave * 64 + lane) * kSizeStride;
+  const uint32_t row8 = SPLIT ? (wave * 64 + lane) * kSizeStride : 0;
 
   // SPLIT: hand the chain over to the wave that owns the next chunk / tell everybody to stop
   auto post = [&](uint32_t ci, uint32_t state, uint32_t e_abs, uint32_t o, bool strad) {
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position
     const uint32_t ci = c0 / kChunk;
     uint32_t entry_off = kIdxNone, out_here = 0, nelem_here = 0;
+    uint32_t szp[4] = {0, 0, 0, 0};  // (block decoder's index) sizes of the elements at positions 0..15, a byte each
     // a verdict inside the loop: write it and, in SPLIT mode, stop the other waves
     auto bail = [&](uint32_t st) {
       finish(st, 0);
@@ -340,7 +344,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
                                    : (!ok ? t_pack(kExitErr, 0, 0) : (inreg ? t_in : t_out_of));
         szb = ok ? szb : 255;
         s_tab[row + k] = t;
-        s_sz[row8 + k] = (uint8_t)szb;
+        if (SPLIT) s_sz[row8 + k] = (uint8_t)szb;
+        else if (k < (int)kSub) szp[k >> 2] |= szb << (8 * (k & 3));
       }
       };
       if (c0 + kChunk + 64 <= n) tabulate(std::true_type{});
@@ -476,7 +481,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     {
       uint32_t pw = entry_off;  // walk to the first element at or after byte 16 (none = 32)
       while (ballot(pw < kSub)) {
-        if (pw < kSub) pw += s_sz[row8 + pw];
+        const uint32_t wv = pw < 4 ? szp[0] : (pw < 8 ? szp[1] : (pw < 12 ? szp[2] : szp[3]));
+        if (pw < kSub) pw += (wv >> ((pw & 3) * 8)) & 0xffu;
       }
       uint32_t out_second = 0, nc_second = 0;
       if (entry_off != kIdxNone && pw < kRegion && rs + pw < n) {  // an element in the second half
