@@ -498,6 +498,9 @@ def main():
                 "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
                 "index_pass_kernel_ms": round(idx_ms, 4),
                 "passed_on_units_kernel_ms": round(dec2_ms, 4),
+                # turns the indexed decoder gave up on after its bounded wait (must be 0; each costs ~30 ms and
+                # hands its unit to the one-pass kernel)
+                "decode_turns_given_up": int(ctx.kernel_ms(9)[0]),
                 "launches": dec_launches,
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },

@@ -76,6 +76,7 @@ struct Decode2Params {
   const uint32_t* idx;
   uint64_t n_units;
   int unit;
+  uint32_t* timeouts;  // [1] turns that were given up on (see the resolvers' wait): never, on a consistent index
   int second;  // the launch after the ring-window one: only the units that one passed on (kNeedsWindow)
   const uint32_t* pass_list;  // ... listed by passed_on_list_kernel; pass_list[-2] = how many
   int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
@@ -882,7 +883,10 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         for (uint32_t spin = 0; front < expect; spin++) {
           if ((spin & 1023) == 1023 && (spin > 400000 || s_err != 0)) {
             // cannot happen on a consistent index; never hang the GPU
-            if (lane == 0) atomicOr(&s_err, 4u);
+            if (lane == 0) {
+              atomicOr(&s_err, 4u);
+              if (spin > 400000 && prm.timeouts) atomicAdd(prm.timeouts, 1u);
+            }
             break;
           }
           front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));

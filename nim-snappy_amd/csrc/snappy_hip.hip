@@ -118,6 +118,7 @@ struct snappy_hip_ctx {
   uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
+  uint32_t* d_counters = nullptr;  // [16] [0] turns the indexed decoder gave up on (kernel_ms slot 9)
   DevBuf ws[24];                   // grow-only workspace of the host-buffer API
   bool timing = false;
   struct Timed {
@@ -249,6 +250,8 @@ int ctx_init(snappy_hip_ctx* c) {
   HIP_TRY(hipMemcpy(c->d_col_mul, mul.data(), mul.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_seq_off, so.data(), so.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_seq_step, ss.data(), ss.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&c->d_counters, 64));
+  HIP_TRY(hipMemset(c->d_counters, 0, 64));
   return SNAPPY_HIP_OK;
 }
 }  // namespace
@@ -287,6 +290,7 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_col_mul);
   (void)hipFree(c->d_seq_off);
   (void)hipFree(c->d_seq_step);
+  (void)hipFree(c->d_counters);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -325,6 +329,12 @@ extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_
     (void)hipEventDestroy(t.b);
   }
   c->timed.clear();
+  if (which == 9) {  // not a duration: turns the indexed decoder gave up on since the context was created
+    uint32_t v = 0;
+    if (hipMemcpy(&v, c->d_counters, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    if (launches) *launches = v;
+    return (double)v;
+  }
   if (which < 0 || which >= kTimeSlots) return 0;
   if (launches) *launches = c->ms_cnt[which];
   return c->ms_cnt[which] ? c->ms_sum[which] / (double)c->ms_cnt[which] : 0.0;
@@ -525,6 +535,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     ip.n_units = n_units;
     ip.unit = unit;
     Decode2Params dp{};
+    dp.timeouts = c->d_counters;
     dp.in = d_in;
     dp.in_off = d_in_off;
     dp.in_len = d_in_len;
