@@ -1,4 +1,6 @@
-"""Probe: does the decode kernel scale with more workgroups per CU?  Units of 32 KiB blocks decoded with
+"""(historic: the -DD2_WINDOW / -DD2_MINWAVES builds it compared existed at commit 72bbb48; the result --
+three workgroups per CU scale -- became the ring-window instantiation of decode2_kernel.h)
+Probe: does the decode kernel scale with more workgroups per CU?  Units of 32 KiB blocks decoded with
 the 64 KiB window (two workgroups per CU) and with a 32 KiB window (three per CU): same work per block."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
