@@ -12,6 +12,15 @@ workload: configs[1] of BASELINE.json -- 1 x MI355X block DECOMPRESS of 65 536 x
           (configs[2], configs[3]) as extra keys; `value` is the decompress rate.
 multi-GPU: every rank owns its own 65 536-block range of the corpus (weak scaling, no data-path
           collective -- blocks are independent); value = all ranks' bytes / max time.
+          `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF (a child
+          `python -m torch.distributed.run`, before this process touches a GPU), relays rank 0's JSON
+          line and exits with the child's code; under an external launcher it checks WORLD_SIZE == N.
+sharded_compress: BASELINE configs[4] inside the same line -- a FIXED total (32 GiB, or what fits) split
+          N ways by block range (tools/shard.split_range), every rank encodes + packs its shard, the N
+          shard totals are exchanged and scanned (the reference's serial `written += ...`,
+          snappy.nim:56-62,146-153), every shard is copied to its offset in ONE page-locked host buffer
+          (a shared mapping all ranks register); strong_GBps = total bytes / slowest rank, and the stream's
+          digest is compared with a single-GPU encoding of the same bytes.
 
 roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel<32768> (pass 2
           of the v2 decoder, ring-window instantiation; pass 1, index_units_kernel, and the whole-block
@@ -44,8 +53,8 @@ HBM_PEAK_GBPS = 8000.0
 BLOCK = 65536
 
 
-def measured_traffic(nb, only):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_bench.sh
+def measured_traffic(nb, only, kernels=("decode_indexed_kernel<32768>", "decode_indexed_kernel")):
+    """HBM bytes per launch of a kernel from the PMC passes of tools/profile_bench.sh
     (FETCH_SIZE / WRITE_SIZE cannot be read inside this process: they need their own rocprofv3
     passes).  The committed measurement is for the default workload only; anything else: None."""
     if nb != 65536 or only is not None:
@@ -55,11 +64,14 @@ def measured_traffic(nb, only):
         return None
     with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
         t = json.load(f)
-    k = t.get("kernels", {}).get("decode_indexed_kernel<32768>") or t.get("kernels", {}).get("decode_indexed_kernel")
-    return None if k is None else k["total_bytes"]
+    for name in kernels:
+        k = t.get("kernels", {}).get(name)
+        if k is not None:
+            return k["total_bytes"]
+    return None
 
 
-def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
+def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_all):
     """Oracle (CPU port of the reference) on the first n_sample blocks, one thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes
@@ -90,50 +102,50 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s):
         passes += 1
         assert st == 0
     assert np.array_equal(dec, src)
-    # the same sample, block ranges spread over all host threads (SURVEY 8d "B2"; ctypes releases the GIL)
-    import concurrent.futures as cf
-    nthr = min(os.cpu_count() or 1, 64, n_sample)
-    per = (n_sample + nthr - 1) // nthr
+    # SURVEY 8d "B2 ... all host cores": the oracle over every host CPU (native threads inside the oracle: runs
+    # of 8 blocks from a shared counter), on a larger sample so that every thread has work; 64 threads beside it
+    ncpu = os.cpu_count() or 1
+    n_mt = min(nb_all, max(n_sample, 32768))
+    src_mt = d_in[:n_mt * BLOCK].cpu().numpy()
+    out2 = np.empty(n_mt * slot, dtype=np.uint8)
+    csz2 = np.empty(n_mt, dtype=np.uint32)
+    offs2 = (np.arange(n_mt, dtype=np.uint64) * slot)
+    dec2 = np.empty(n_mt * BLOCK, dtype=np.uint8)
 
-    def part(k):
-        lo, hi = k * per, min(n_sample, (k + 1) * per)
-        if lo >= hi:
-            return 0
-        return orc.lib.sor_uncompress_blocks(out.ctypes.data, offs[lo:].ctypes.data, csz[lo:].ctypes.data,
-                                             hi - lo, dec.ctypes.data + lo * BLOCK, BLOCK)
+    def mt_rates(nthr):
+        best_e, best_d = 0.0, 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.lib.sor_compress_blocks_mt(src_mt.ctypes.data, src_mt.size, BLOCK, out2.ctypes.data, slot,
+                                           csz2.ctypes.data, nthr)
+            best_e = max(best_e, n_mt * BLOCK / (time.perf_counter() - t0) / 1e9)
+        for _ in range(4):
+            t0 = time.perf_counter()
+            st = orc.lib.sor_uncompress_blocks_mt(out2.ctypes.data, offs2.ctypes.data, csz2.ctypes.data, n_mt,
+                                                  dec2.ctypes.data, BLOCK, nthr)
+            best_d = max(best_d, n_mt * BLOCK / (time.perf_counter() - t0) / 1e9)
+            assert st == 0
+        return round(best_d, 3), round(best_e, 3)
 
-    def cpart(k):  # compress, block ranges spread over the same threads
-        lo, hi = k * per, min(n_sample, (k + 1) * per)
-        if lo < hi:
-            orc.lib.sor_compress_blocks(src.ctypes.data + lo * BLOCK, (hi - lo) * BLOCK, BLOCK,
-                                        out2.ctypes.data + lo * slot, slot, csz2.ctypes.data + 4 * lo)
-        return 0
-
-    out2 = np.empty(n_sample * slot, dtype=np.uint8)
-    csz2 = np.empty(n_sample, dtype=np.uint32)
-    with cf.ThreadPoolExecutor(nthr) as ex:
-        list(ex.map(part, range(nthr)))  # warm
-        t0 = time.perf_counter()
-        mt_passes = 4
-        for _ in range(mt_passes):
-            assert all(r == 0 for r in ex.map(part, range(nthr)))
-        t_mt = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        list(ex.map(cpart, range(nthr)))
-        t_mt_enc = time.perf_counter() - t0
-    assert np.array_equal(csz2, csz)
+    all_d, all_e = mt_rates(ncpu)
+    assert np.array_equal(csz2[:n_sample], csz) and np.array_equal(dec2, src_mt)
+    t64_d, t64_e = mt_rates(min(64, ncpu)) if ncpu > 64 else (all_d, all_e)
     return {
         "value": round(n_sample * BLOCK * passes / t_dec / 1e9, 4),
         "unit": "GB/s uncompressed (decompress)",
         "cores": 1,
         "kind": "port",
         "sample": "first %d blocks (%d MiB) of the same corpus, %d decode passes; "
-                  "oracle/snappy_oracle.c -O3, one thread" % (n_sample, n_sample // 16, passes),
+                  "oracle/snappy_oracle.c -O3, one thread (threaded legs: first %d blocks, best of 3-4 passes)"
+                  % (n_sample, n_sample // 16, passes, n_mt),
         "compress_value": round(n_sample * BLOCK / t_enc / 1e9, 4),
-        "threads": nthr,
-        "threads_value": round(n_sample * BLOCK * mt_passes / t_mt / 1e9, 3),
-        "compress_threads_value": round(n_sample * BLOCK / t_mt_enc / 1e9, 3),
-        "host_cpus": os.cpu_count(),
+        # every host CPU (os.cpu_count() threads), and 64 threads as a second figure
+        "threads": ncpu,
+        "threads_value": all_d,
+        "compress_threads_value": all_e,
+        "threads64_value": t64_d,
+        "compress_threads64_value": t64_e,
+        "host_cpus": ncpu,
     }
 
 
@@ -309,6 +321,256 @@ def per_class_rates(hip, corpus, ctx, dev, nb):
     return out
 
 
+def _tree_sha256(buf, n, piece=64 << 20, threads=16):
+    """sha256 over the per-piece sha256 digests of buf[0:n] (pieces of 64 MiB of the STREAM, so the digest
+    does not depend on how the stream was sharded); pieces are hashed on several threads."""
+    import concurrent.futures as cf
+    import hashlib
+    mv = memoryview(buf)[:n]
+
+    def one(i):
+        return hashlib.sha256(mv[i:min(n, i + piece)]).digest()
+
+    with cf.ThreadPoolExecutor(threads) as ex:
+        digs = list(ex.map(one, range(0, max(n, 1), piece)))
+    return hashlib.sha256(b"".join(digs)).hexdigest()
+
+
+def _host_room_bytes():
+    """What this process may take of host memory: MemAvailable, capped by the cgroup's limit."""
+    room = None
+    try:
+        import psutil
+        room = int(psutil.virtual_memory().available)
+    except Exception:
+        pass
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(f).read().strip()
+            if v.isdigit():
+                lim = int(v)
+                used = 0
+                for g in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                    try:
+                        used = int(open(g).read().strip())
+                        break
+                    except Exception:
+                        pass
+                room = min(room, lim - used) if room is not None else lim - used
+        except Exception:
+            pass
+    try:
+        st = os.statvfs("/dev/shm")
+        shm = st.f_bavail * st.f_frsize
+        room = min(room, shm) if room is not None else shm
+    except Exception:
+        pass
+    return room if room is not None else 8 << 30
+
+
+def sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, total_blocks, requested_blocks):
+    """BASELINE configs[4]: block-range sharded compress of a FIXED corpus (strong scaling) with the host-side
+    concatenate.  Rank r owns blocks split_range(r, world, total_blocks) (resident in its HBM before the timed
+    region), encodes them as framed chunks (encodeFrame, encoder.nim:385-426) and packs them; the ONE exchange is
+    an all_gather of the shard totals, whose exclusive scan (the reference's serial `written += ...`,
+    snappy.nim:56-62,146-153) places every shard in the ONE host buffer -- a /dev/shm mapping every rank has
+    page-locked -- and each rank's copy lands there over its own GPU's link.  No data-path collective."""
+    import mmap
+    dd = dist if world > 1 else None
+    cdev = dev if backend == "nccl" else None
+    lo, hi = shard.split_range(rank, world, total_blocks)
+    nbk = hi - lo
+    PIECE = 65536  # blocks per encode launch (4 GiB: the slots of one launch take 5 GB)
+    d_sh = torch.empty(nbk * BLOCK, dtype=torch.uint8, device=dev)
+    for b0 in range(0, nbk, 4096):
+        c = min(4096, nbk - b0)
+        d_sh[b0 * BLOCK:(b0 + c) * BLOCK] = corpus.make_blocks_torch(torch, lo + b0, c, dev).reshape(-1)
+    pc = min(PIECE, max(nbk, 1))
+    d_slots = torch.empty(pc * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
+    d_sizes = torch.empty(pc, dtype=torch.int32, device=dev)
+    d_offsets = torch.empty(pc + 1, dtype=torch.int64, device=dev)
+
+    def encode_shard(d_packed):
+        """encode + pack every piece of the shard behind the one before it; returns the shard's bytes"""
+        at = 0
+        for b0 in range(0, nbk, PIECE):
+            c = min(PIECE, nbk - b0)
+            ctx.encode_blocks(d_sh[b0 * BLOCK:(b0 + c) * BLOCK], c * BLOCK, d_slots, d_sizes, unit=hip.UNIT_FRAME)
+            if d_packed is None:  # sizing pass: totals only
+                ctx.sync()
+                at += int(d_sizes[:c].to(torch.int64).sum().item())
+            else:
+                ctx.pack(d_slots, d_sizes, c, d_packed, d_offsets, base=at)
+                ctx.sync()
+                at = int(d_offsets[c].item())
+        return at
+
+    def exchange(mine):
+        """the one exchange: N shard totals -> exclusive scan"""
+        totals = [mine]
+        if world > 1:
+            t = torch.tensor([mine], dtype=torch.int64, device=cdev if cdev is not None else "cpu")
+            got = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(got, t)
+            totals = [int(g.item()) for g in got]
+        offs = [10]
+        for v in totals:
+            offs.append(offs[-1] + v)
+        return totals, offs
+
+    mine = encode_shard(None)  # warm-up + sizes (the encoding is deterministic)
+    totals0, offs0 = exchange(mine)
+    stream_len = offs0[-1]
+    d_packed = torch.empty(mine + 64, dtype=torch.uint8, device=dev)
+    # the ONE host buffer: a shared mapping, page-locked by every rank (the caller's output buffer of
+    # snappy_hip_compress_shards, here shared between processes)
+    path = "/dev/shm/snappy_bench_%s_%d.bin" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+    if rank == 0:
+        with open(path, "wb") as fh:
+            fh.truncate(stream_len)
+    if world > 1:
+        dist.barrier()
+    fh = open(path, "r+b")
+    mm = mmap.mmap(fh.fileno(), stream_len)
+    host = np.frombuffer(mm, dtype=np.uint8)
+    my_off, my_len = offs0[rank], totals0[rank]
+    h_slice = torch.from_numpy(host[my_off:my_off + my_len]) if my_len else None
+    pinned = False
+    if my_len:
+        h_slice[::4096] = 0  # touch (shm pages are allocated on first touch)
+        try:
+            pinned = int(torch.cuda.cudart().cudaHostRegister(h_slice.data_ptr(), my_len, 0)) == 0
+        except Exception:
+            pinned = False
+    if rank == 0:
+        host[:10] = np.frombuffer(bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]), dtype=np.uint8)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        got = encode_shard(d_packed)
+        totals, offs = exchange(got)
+        assert totals == totals0 and offs == offs0, "shard totals changed between two encodings"
+        if my_len:
+            h_slice.copy_(d_packed[:my_len], non_blocking=True)
+        torch.cuda.synchronize()
+        t_rank = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        t = shard.max_over_ranks(dd, t_rank, cdev)
+        best = t if best is None else min(best, t)
+    enc_only = None
+    ctx.timing(True)
+    encode_shard(d_packed)
+    enc_only = ctx.kernel_ms(1)[0]
+    ctx.timing(False)
+    if pinned:
+        torch.cuda.cudart().cudaHostUnregister(h_slice.data_ptr())
+    if world > 1:
+        dist.barrier()
+    res = None
+    if rank == 0:
+        digest = _tree_sha256(mm, stream_len)
+        # the same bytes from ONE GPU: this rank encodes every block range itself, piece by piece, and the packed
+        # chunks are compared byte for byte with the host buffer (equal bytes: equal digests)
+
+        def same(d_t, n, at):
+            for c0 in range(0, n, 256 << 20):
+                c1 = min(n, c0 + (256 << 20))
+                if not np.array_equal(d_t[c0:c1].cpu().numpy(), host[at + c0:at + c1]):
+                    return False
+            return True
+
+        if world == 1:
+            equal = same(d_packed, mine, 10)  # (d_packed holds a later, separate encoding than the one copied out)
+        else:
+            equal, at = True, 10
+            d_tmp = torch.empty(min(PIECE, total_blocks) * BLOCK, dtype=torch.uint8, device=dev)
+            for b0 in range(0, total_blocks, PIECE):
+                c = min(PIECE, total_blocks - b0)
+                for g0 in range(0, c, 4096):
+                    g = min(4096, c - g0)
+                    d_tmp[g0 * BLOCK:(g0 + g) * BLOCK] = corpus.make_blocks_torch(torch, b0 + g0, g, dev).reshape(-1)
+                big = c > pc
+                sl = torch.empty(c * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev) if big else d_slots
+                sz = torch.empty(c, dtype=torch.int32, device=dev) if big else d_sizes
+                of = torch.empty(c + 1, dtype=torch.int64, device=dev) if big else d_offsets
+                ctx.encode_blocks(d_tmp[:c * BLOCK], c * BLOCK, sl, sz, unit=hip.UNIT_FRAME)
+                ctx.sync()
+                tot = int(sz[:c].to(torch.int64).sum().item())
+                d_pk = torch.empty(tot + 64, dtype=torch.uint8, device=dev)
+                ctx.pack(sl, sz, c, d_pk, of, base=0)
+                ctx.sync()
+                equal = equal and at + tot <= stream_len and same(d_pk, tot, at)
+                at += tot
+                del d_pk, sl, sz, of
+            equal = equal and at == stream_len
+            del d_tmp
+        if not np.array_equal(host[:10], np.frombuffer(bytes([0xff, 6, 0, 0, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]), dtype=np.uint8)):
+            equal = False
+        u = total_blocks * BLOCK
+        res = {
+            "what": "BASELINE configs[4]: block-range sharded compressFramed, N shard totals -> host scan -> every "
+                    "shard copied to its offset in ONE page-locked host buffer; fixed total (strong scaling)",
+            "total_blocks": total_blocks,
+            "uncompressed_bytes": u,
+            "reduced_from_blocks": requested_blocks if requested_blocks != total_blocks else None,
+            "stream_bytes": stream_len,
+            "n_shards": world,
+            "shard_bytes": totals0,
+            "shard_offsets": offs0,
+            "seconds": round(best, 5),
+            "strong_GBps": round(u / best / 1e9, 3),
+            "encode_kernel_ms_rank0": round(enc_only, 3),
+            "host_buffer_page_locked": pinned,
+            "stream_sha256_tree64MiB": digest,  # sha256 of the sha256 digests of the stream's 64 MiB pieces
+            # a single-GPU encoding of all blocks on rank 0, compared byte for byte with the host buffer
+            "equals_single_gpu_sha256": bool(equal),
+        }
+        if not res["equals_single_gpu_sha256"]:
+            raise SystemExit("bench: the sharded stream differs from the single-GPU stream")
+    del host, h_slice
+    try:
+        mm.close()
+    except BufferError:
+        pass
+    fh.close()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    del d_sh, d_slots, d_packed
+    return res
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as a CHILD (this process has not touched a GPU and never
+    does), relay rank 0's JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(proc.returncode if proc.returncode else (0 if lines else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,11 +580,18 @@ def main():
     ap.add_argument("--only", default=None, help="one corpus class (per-class numbers)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=8192)
+    ap.add_argument("--shard-gib", type=float, default=None,
+                    help="fixed total of the sharded-compress leg (default 32 GiB = 8 x --blocks; 0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     # test hook: BENCH_SHARE_DEVICE=1 BENCH_DIST_BACKEND=gloo lets several ranks share GPU 0, so that
     # the N > 1 code path can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
     if os.environ.get("BENCH_SHARE_DEVICE"):
@@ -456,6 +725,33 @@ def main():
     torch.cuda.synchronize()
     copy_gbps = 3 * 2 * nb * BLOCK / (time.perf_counter() - t0) / 1e9
 
+    # ---- BASELINE configs[4]: fixed-total block-range sharded compress with the host concatenate -------------
+    sharded = None
+    want_blocks = 8 * nb if args.shard_gib is None else int(args.shard_gib * (1 << 30)) // BLOCK
+    if want_blocks > 0 and args.only is None:
+        total_blocks = max(world, want_blocks)
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        room = _host_room_bytes()
+        while total_blocks > world:
+            per_rank = (total_blocks + world - 1) // world * BLOCK
+            gpu_need = per_rank * 1.6 + min(65536, per_rank // BLOCK) * hip.SLOT_STRIDE + (4 << 30)
+            if os.environ.get("BENCH_SHARE_DEVICE"):
+                gpu_need *= world
+            host_need = 0.6 * total_blocks * BLOCK * 2.5 + (2 << 30)
+            if gpu_need <= free_b and host_need <= room:
+                break
+            total_blocks //= 2
+        if world > 1:  # every rank must use the same total: the smallest anyone can afford
+            t = torch.tensor([total_blocks], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            total_blocks = int(t.item())
+        sharded = sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, total_blocks, want_blocks)
+
+    give_ups = int(ctx.kernel_ms(9)[0])
+    if give_ups:
+        raise SystemExit("bench: the indexed decoder gave up on %d turns (each hands its unit to the one-pass "
+                         "kernel at ~30 ms): the number is void" % give_ups)
+
     if rank == 0:
         u_bytes = nb * BLOCK
         value = world * u_bytes * args.steps / elapsed / 1e9
@@ -500,12 +796,25 @@ def main():
                 "passed_on_units_kernel_ms": round(dec2_ms, 4),
                 # turns the indexed decoder gave up on after its bounded wait (must be 0; each costs ~30 ms and
                 # hands its unit to the one-pass kernel)
-                "decode_turns_given_up": int(ctx.kernel_ms(9)[0]),
+                "decode_turns_given_up": give_ups,
                 "launches": dec_launches,
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },
             "compress_GBps": round(world * u_bytes / t_enc / 1e9, 3),
             "compress_kernel_ms": round(enc_ms, 3),
+            # the encode kernel against the same roofline (compress = U + C algorithmic bytes)
+            "roofline_compress": {
+                "bound": "hbm",
+                "achieved": round((u_bytes + sum_c) / (enc_ms * 1e-3) / 1e9, 2) if enc_ms else 0.0,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round((u_bytes + sum_c) / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if enc_ms else 0.0,
+                "traffic": measured_traffic(nb, args.only, ("encode_blocks_kernel",)),
+                "kernel": "encode_blocks_kernel",
+                "kernel_ms": round(enc_ms, 4),
+                "algorithmic_bytes_per_launch": sum_c + u_bytes,
+            },
+            "sharded_compress": sharded,
             # compress + decompress of the same bytes, one after the other (BASELINE's metric names both)
             "roundtrip_GBps": round(world * u_bytes / (t_enc + elapsed / args.steps) / 1e9, 3),
             # one genuine framed stream (10-byte identifier + one chunk per block), stream and output in HBM
@@ -517,7 +826,11 @@ def main():
             offs = d_offsets.cpu().numpy()
             sizes = d_sizes.cpu().numpy()
             ns = min(args.cpu_blocks, nb)
-            line["cpu_baseline"] = cpu_baseline(corpus, d_in, d_packed, offs, sizes, ns, 10.0)
+            line["cpu_baseline"] = cpu_baseline(corpus, d_in, d_packed, offs, sizes, ns, 10.0, nb)
+            cb = line["cpu_baseline"]
+            line["gpu_over_all_host_cpus"] = {
+                "compress": round(line["compress_GBps"] / cb["compress_threads_value"], 2),
+                "decompress": round(line["value"] / cb["threads_value"], 2), "host_cpus": cb["host_cpus"]}
             line["config1_alice29"] = config1_alice29(hip)
             del d_packed, d_out
             line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 8192))

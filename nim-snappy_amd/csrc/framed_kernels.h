@@ -488,9 +488,11 @@ __global__ __launch_bounds__(256) void frame_scatter_kernel(FrameScatterParams p
   }
   if (!ok || j >= nc) return;
   const uint64_t pos = p.pos[j];
-  const uint32_t crc = ld32u(p.in + pos + 4);
   const uint32_t data_len = ld_hdr(p.in, pos) >> 8;
   const uint32_t seq = (uint32_t)(p.comp_at[j] + p.stored_at[j]);
+  // the CRC field exists only in data chunks (frame_fill verified data_len >= 4 for them); a skippable or
+  // padding chunk of fewer than 4 bytes may end the stream, and pos + 4 is then the end of the caller's buffer
+  const uint32_t crc = (p.is_comp[j] || p.is_stored[j]) ? ld32u(p.in + pos + 4) : 0u;
   if (p.is_comp[j]) {
     const uint32_t k = (uint32_t)p.comp_at[j];
     p.comp.in_off[k] = pos + 8;

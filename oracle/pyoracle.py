@@ -57,6 +57,14 @@ def _load():
                                         ctypes.c_void_p]
     lib.sor_uncompress_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, sz,
                                           ctypes.c_void_p, sz]
+    lib.sor_compress_blocks_mt.restype = None
+    lib.sor_compress_blocks_mt.argtypes = [ctypes.c_void_p, sz, sz, ctypes.c_void_p, sz,
+                                           ctypes.c_void_p, ctypes.c_int]
+    lib.sor_encode_frames_mt.restype = None
+    lib.sor_encode_frames_mt.argtypes = [ctypes.c_void_p, sz, sz, ctypes.c_void_p, sz,
+                                         ctypes.c_void_p, ctypes.c_int]
+    lib.sor_uncompress_blocks_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, sz,
+                                             ctypes.c_void_p, sz, ctypes.c_int]
     return lib
 
 

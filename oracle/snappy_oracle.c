@@ -527,3 +527,90 @@ int sor_uncompress_blocks(const uint8_t* in, const uint64_t* offsets, const uint
   }
   return SOR_OK;
 }
+
+/* ---- the same two batch helpers over n_threads host threads (bench.py's all-cores leg, SURVEY 8d
+ * "B2 ... all host cores"): blocks are independent, threads take runs of 8 blocks from a shared
+ * counter.  Plain pthreads; the reference itself is single-threaded (tests/benchmark.nim:93-126). */
+#include <pthread.h>
+#include <stdatomic.h>
+
+typedef struct {
+  const uint8_t* in;
+  size_t total_len, block_len, slot, n_blocks;
+  uint8_t* out;
+  uint32_t* sizes;
+  const uint64_t* offsets;
+  atomic_size_t next;
+  atomic_int status;
+  int decode; /* 0 compress (raw buffers), 1 uncompress, 2 encodeFrame (framed chunks) */
+} sor_mt_job;
+
+static void* sor_mt_worker(void* arg) {
+  sor_mt_job* j = (sor_mt_job*)arg;
+  const size_t run = 8;
+  for (;;) {
+    size_t b0 = atomic_fetch_add(&j->next, run);
+    if (b0 >= j->n_blocks) break;
+    size_t b1 = b0 + run < j->n_blocks ? b0 + run : j->n_blocks;
+    for (size_t i = b0; i < b1; i++) {
+      size_t w;
+      if (j->decode == 1) {
+        int st = sor_uncompress(j->in + j->offsets[i], j->sizes[i], j->out + i * j->block_len,
+                                j->block_len, &w);
+        if (st != SOR_OK) atomic_store(&j->status, st);
+      } else {
+        size_t off = i * j->block_len;
+        size_t bl = j->total_len - off < j->block_len ? j->total_len - off : j->block_len;
+        if (j->decode == 2)
+          w = sor_encode_frame(j->in + off, bl, j->out + i * j->slot);
+        else
+          sor_compress(j->in + off, bl, j->out + i * j->slot, j->slot, &w);
+        j->sizes[i] = (uint32_t)w;
+      }
+    }
+  }
+  return NULL;
+}
+
+static int sor_mt_run(sor_mt_job* j, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 1024) n_threads = 1024;
+  pthread_t th[1024];
+  int started = 0;
+  atomic_init(&j->next, 0);
+  atomic_init(&j->status, SOR_OK);
+  for (int t = 1; t < n_threads; t++) {
+    if (pthread_create(&th[started], NULL, sor_mt_worker, j) != 0) break;
+    started++;
+  }
+  sor_mt_worker(j);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  return atomic_load(&j->status);
+}
+
+void sor_compress_blocks_mt(const uint8_t* in, size_t total_len, size_t block_len, uint8_t* out,
+                            size_t slot, uint32_t* sizes, int n_threads) {
+  sor_mt_job j;
+  memset(&j, 0, sizeof j);
+  j.in = in, j.total_len = total_len, j.block_len = block_len, j.out = out, j.slot = slot;
+  j.sizes = sizes, j.n_blocks = (total_len + block_len - 1) / block_len, j.decode = 0;
+  (void)sor_mt_run(&j, n_threads);
+}
+
+int sor_uncompress_blocks_mt(const uint8_t* in, const uint64_t* offsets, const uint32_t* sizes,
+                             size_t n_blocks, uint8_t* out, size_t block_len, int n_threads) {
+  sor_mt_job j;
+  memset(&j, 0, sizeof j);
+  j.in = in, j.offsets = offsets, j.sizes = (uint32_t*)sizes, j.n_blocks = n_blocks, j.out = out;
+  j.block_len = block_len, j.decode = 1;
+  return sor_mt_run(&j, n_threads);
+}
+
+void sor_encode_frames_mt(const uint8_t* in, size_t total_len, size_t block_len, uint8_t* out,
+                          size_t slot, uint32_t* sizes, int n_threads) {
+  sor_mt_job j;
+  memset(&j, 0, sizeof j);
+  j.in = in, j.total_len = total_len, j.block_len = block_len, j.out = out, j.slot = slot;
+  j.sizes = sizes, j.n_blocks = (total_len + block_len - 1) / block_len, j.decode = 2;
+  (void)sor_mt_run(&j, n_threads);
+}

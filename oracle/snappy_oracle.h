@@ -82,6 +82,15 @@ void sor_compress_blocks(const uint8_t* in, size_t total_len, size_t block_len, 
 int sor_uncompress_blocks(const uint8_t* in, const uint64_t* offsets, const uint32_t* sizes,
                           size_t n_blocks, uint8_t* out, size_t block_len);
 
+/* The same over n_threads host threads (bench.py's all-cores leg; blocks are independent). */
+void sor_compress_blocks_mt(const uint8_t* in, size_t total_len, size_t block_len, uint8_t* out,
+                            size_t slot, uint32_t* sizes, int n_threads);
+/* encodeFrame (encoder.nim:385-426) of every block: framed chunks, slot >= 8 + max_compressed_len(block_len) */
+void sor_encode_frames_mt(const uint8_t* in, size_t total_len, size_t block_len, uint8_t* out,
+                          size_t slot, uint32_t* sizes, int n_threads);
+int sor_uncompress_blocks_mt(const uint8_t* in, const uint64_t* offsets, const uint32_t* sizes,
+                             size_t n_blocks, uint8_t* out, size_t block_len, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

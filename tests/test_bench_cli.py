@@ -1,0 +1,58 @@
+"""bench.py's launcher contract, as far as a box without a GPU can check it: `--gpus N` must agree with
+WORLD_SIZE under an external launcher, and without one bench.py starts the N ranks itself as a child process
+(before it touches a GPU) and hands the child's exit code on."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_flag_must_match_world_size():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--blocks", "16"], capture_output=True, text=True,
+                       timeout=300, env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_self_launch_relays_the_childs_exit_code():
+    """no GPU here: the two ranks the parent starts fail at their first GPU call, and the parent -- which never
+    initialised a GPU itself -- exits non-zero without printing a JSON line"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: the self-launch path is covered by the -m gpu bench test")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--blocks", "16", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_threaded_oracle_helpers_equal_the_serial_ones(orc):
+    import corpus
+    nb, slot = 40, 76800
+    b = corpus.make_blocks(100, nb).reshape(-1)
+    o = np.empty(nb * slot, np.uint8)
+    s = np.empty(nb, np.uint32)
+    o1 = np.empty(nb * slot, np.uint8)
+    s1 = np.empty(nb, np.uint32)
+    orc.lib.sor_compress_blocks_mt(b.ctypes.data, b.size, 65536, o.ctypes.data, slot, s.ctypes.data, 5)
+    orc.lib.sor_compress_blocks(b.ctypes.data, b.size, 65536, o1.ctypes.data, slot, s1.ctypes.data)
+    assert (s == s1).all()
+    assert all((o[i * slot:i * slot + s[i]] == o1[i * slot:i * slot + s[i]]).all() for i in range(nb))
+    d = np.empty(nb * 65536, np.uint8)
+    offs = np.arange(nb, dtype=np.uint64) * slot
+    assert orc.lib.sor_uncompress_blocks_mt(o.ctypes.data, offs.ctypes.data, s.ctypes.data, nb, d.ctypes.data, 65536, 7) == 0
+    assert (d == b).all()
+    orc.lib.sor_encode_frames_mt(b.ctypes.data, b.size, 65536, o.ctypes.data, slot, s.ctypes.data, 3)
+    fr = b"".join(o[i * slot:i * slot + s[i]].tobytes() for i in range(nb))
+    assert bytes([0xff, 6, 0, 0, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]) + fr == orc.encode_framed(b.tobytes())

@@ -219,10 +219,11 @@ def test_dense_copy_stream_takes_one_pass_kernel(hip, orc):
     assert hip.decode(bytes(s2)) == orc.decode(bytes(s2)) != b""
 
 
-def test_full_size_round_trip_properties(hip, torch_mod):
+def test_full_size_round_trip_properties(hip, orc, torch_mod):
     """BASELINE size (65 536 x 64 KiB = 4 GiB; SNAPPY_HIP_TEST_BLOCKS overrides): compress ->
     pack -> decompress on the device restores every byte, all statuses ok, packed offsets
-    monotone and consistent with the sizes, framed CRC-of-output equals CRC-of-input."""
+    monotone and consistent with the sizes, framed CRC-of-output equals CRC-of-input; and every packed
+    raw unit and the whole framed stream equal the oracle's encoding byte for byte."""
     import corpus
     torch = torch_mod
     nb = int(os.environ.get("SNAPPY_HIP_TEST_BLOCKS", "65536"))
@@ -255,6 +256,37 @@ def test_full_size_round_trip_properties(hip, torch_mod):
     assert int((d_out_len != 65536).sum().item()) == 0
     assert bool(torch.equal(d_dec, d_in))
     assert bool(torch.equal(d_crc, d_crc_in))
+    del d_dec, d_slots
+    # BASELINE configs[2] and [3] at FULL size, byte for byte: the oracle encodes every block on all host threads
+    # (ranges of 8 192 blocks bound the host memory) -- sizes, the packed raw units and the ONE framed stream
+    import hashlib
+    nthr = os.cpu_count() or 1
+    fcap = hip.max_compressed_len_framed(nb * 65536)
+    d_fstream = torch.empty(fcap, dtype=torch.uint8, device="cuda")
+    flen = ctx.compress_framed(d_in, nb * 65536, d_fstream, fcap)
+    assert bytes(d_fstream[:10].cpu().numpy().tobytes()) == cases.FRAMING_HEADER
+    slot = hip.SLOT_STRIDE
+    f_at = 10
+    sha_gpu, sha_orc = hashlib.sha256(), hashlib.sha256()
+    for b0 in range(0, nb, 8192):
+        c = min(8192, nb - b0)
+        src = d_in[b0 * 65536:(b0 + c) * 65536].cpu().numpy()
+        buf = np.empty(c * slot, dtype=np.uint8)
+        csz = np.empty(c, dtype=np.uint32)
+        orc.lib.sor_compress_blocks_mt(src.ctypes.data, src.size, 65536, buf.ctypes.data, slot, csz.ctypes.data, nthr)
+        assert np.array_equal(csz.astype(np.int64), sizes[b0:b0 + c]), b0
+        want = np.concatenate([buf[i * slot:i * slot + int(csz[i])] for i in range(c)])
+        got = d_out[int(offs[b0]):int(offs[b0 + c])].cpu().numpy()
+        assert np.array_equal(got, want), b0
+        sha_gpu.update(got.tobytes())
+        sha_orc.update(want.tobytes())
+        orc.lib.sor_encode_frames_mt(src.ctypes.data, src.size, 65536, buf.ctypes.data, slot, csz.ctypes.data, nthr)
+        want = np.concatenate([buf[i * slot:i * slot + int(csz[i])] for i in range(c)])
+        assert f_at + want.size <= flen, b0
+        assert np.array_equal(d_fstream[f_at:f_at + want.size].cpu().numpy(), want), b0
+        f_at += want.size
+    assert f_at == flen
+    assert sha_gpu.hexdigest() == sha_orc.hexdigest()
     ctx.close()
 
 
@@ -337,15 +369,28 @@ def test_bench_contract_and_two_rank_path(hip):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["dtype"] == "u8" and j["vs_baseline"] is None and j["value"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert j["roofline_compress"]["frac"] > 0 and j["sharded_compress"]["n_shards"] == 1
+    assert j["sharded_compress"]["equals_single_gpu_sha256"] is True
+    # --gpus 2 with NO launcher on the command line: bench.py starts its two ranks itself
     env = dict(os.environ, BENCH_SHARE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533",
-                          os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+    env.pop("WORLD_SIZE", None)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
                          capture_output=True, text=True, timeout=900, env=env)
     lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, two.stdout[-2000:] + two.stderr[-2000:]
+    assert len(lines) == 1 and two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     j2 = json.loads(lines[0])
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["value"] > 0
+    sc = j2["sharded_compress"]
+    assert sc["n_shards"] == 2 and len(sc["shard_bytes"]) == 2 and sc["equals_single_gpu_sha256"] is True
+    # the same fixed total from one and from two shards: the same stream
+    assert sc["total_blocks"] == j["sharded_compress"]["total_blocks"]
+    assert sc["stream_sha256_tree64MiB"] == j["sharded_compress"]["stream_sha256_tree64MiB"]
+    assert sc["stream_bytes"] == j["sharded_compress"]["stream_bytes"]
+    # under an external launcher the flag must agree with WORLD_SIZE
+    env3 = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=300, env=env3)
+    assert bad.returncode != 0
 
 
 def test_sharded_compress_tool_two_ranks(hip):

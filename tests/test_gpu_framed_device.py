@@ -219,3 +219,34 @@ def test_random_framed_streams_match_oracle(dev, orc):
             assert got[0] == exp[0], (it, got[:3], exp[:3])
             if exp[0] == bh.OK:
                 assert got[:3] == tuple(exp[:3]) and got[3] == bytes(exp[3]), it
+
+
+def test_stream_ending_in_a_short_padding_chunk_flush_against_its_allocation(hip, orc):
+    """A skippable / padding chunk with fewer than 4 data bytes may END the stream (`fe 00 00 00`): the parallel
+    chunk walk (streams >= 4 MiB) must not read a CRC field behind such a header.  The stream is padded so that
+    its length is a multiple of 2 MiB and sits in a hipMalloc of exactly its size (no torch allocator)."""
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rt.hipFree.argtypes = [ctypes.c_void_p]
+    src = corpus.make_blocks(0, 160).tobytes()  # 10 MiB: text, html, random (stored chunks), runs
+    body = orc.encode_framed(src)
+    gran = 2 << 20
+    fill = (-(len(body) + 4 + 4)) % gran  # a padding chunk of `fill` bytes, then the 4-byte empty one
+    stream = body + b"\xfe" + bh.le24(fill) + bytes(fill) + b"\xfe\x00\x00\x00"
+    assert len(stream) % gran == 0
+    ctx = hip.Context(0)
+    for tail in (stream, stream[:-4] + b"\x80\x03\x00\x00abc"):
+        # second variant: a skippable chunk with 3 data bytes ends the stream (length no longer a multiple)
+        p_in, p_out = ctypes.c_void_p(), ctypes.c_void_p()
+        assert rt.hipMalloc(ctypes.byref(p_in), len(tail)) == 0 and rt.hipMalloc(ctypes.byref(p_out), len(src)) == 0
+        assert rt.hipMemcpy(p_in, tail, len(tail), 1) == 0
+        got = ctx.uncompress_framed(p_in.value, len(tail), p_out.value, len(src))
+        exp = orc.uncompress_framed(tail, len(src))
+        assert got == (exp[0], exp[1], exp[2]) == (bh.OK, len(tail), len(src))
+        back = ctypes.create_string_buffer(len(src))
+        assert rt.hipMemcpy(back, p_out, len(src), 2) == 0 and back.raw == src
+        rt.hipFree(p_in)
+        rt.hipFree(p_out)
+    ctx.close()
