@@ -127,9 +127,15 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_
             assert st == 0
         return round(best_d, 3), round(best_e, 3)
 
-    all_d, all_e = mt_rates(ncpu)
-    assert np.array_equal(csz2[:n_sample], csz) and np.array_equal(dec2, src_mt)
-    t64_d, t64_e = mt_rates(min(64, ncpu)) if ncpu > 64 else (all_d, all_e)
+    # a sweep of thread counts: boxes with a CPU quota below their CPU count run slower with one thread per CPU
+    sweep = {}
+    for nthr in sorted({ncpu, max(1, ncpu // 2), min(64, ncpu), min(32, ncpu)}, reverse=True):
+        sweep[nthr] = mt_rates(nthr)
+        if nthr == ncpu:
+            assert np.array_equal(csz2[:n_sample], csz) and np.array_equal(dec2, src_mt)
+    all_d = max(v[0] for v in sweep.values())
+    all_e = max(v[1] for v in sweep.values())
+    t64_d, t64_e = sweep[min(64, ncpu)]
     return {
         "value": round(n_sample * BLOCK * passes / t_dec / 1e9, 4),
         "unit": "GB/s uncompressed (decompress)",
@@ -139,10 +145,11 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_
                   "oracle/snappy_oracle.c -O3, one thread (threaded legs: first %d blocks, best of 3-4 passes)"
                   % (n_sample, n_sample // 16, passes, n_mt),
         "compress_value": round(n_sample * BLOCK / t_enc / 1e9, 4),
-        # every host CPU (os.cpu_count() threads), and 64 threads as a second figure
+        # every host CPU: the best of a sweep of thread counts up to os.cpu_count(); 64 threads as a second figure
         "threads": ncpu,
         "threads_value": all_d,
         "compress_threads_value": all_e,
+        "threads_sweep_decompress_compress_GBps": {str(k): list(v) for k, v in sweep.items()},
         "threads64_value": t64_d,
         "compress_threads64_value": t64_e,
         "host_cpus": ncpu,

@@ -127,34 +127,41 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
 // ============================================================================================
 constexpr uint32_t kScanThreads = 1024;
 
-// offsets[0] = base, offsets[i+1] = offsets[i] + sizes[i].  One workgroup, chunked.
+// offsets[0] = base, offsets[i+1] = offsets[i] + sizes[i].  One workgroup; a pass takes 8 192 sizes (eight
+// consecutive ones per thread: their prefix in registers, one DPP scan of the threads' sums per wave, the
+// sixteen wave sums through LDS), so 65 536 sizes are eight passes of two barriers each.
 __global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t* sizes,
                                                                   uint64_t n, uint64_t base,
                                                                   uint64_t* offsets) {
-  __shared__ uint64_t s_wave[kScanThreads / 64];
-  __shared__ uint64_t s_carry;
+  constexpr uint32_t kPer = 8;
+  __shared__ uint32_t s_wave[2][kScanThreads / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t == 0) {
-    s_carry = base;
-    offsets[0] = base;
-  }
-  __syncthreads();
-  for (uint64_t c = 0; c < n; c += kScanThreads) {
-    const uint64_t i = c + t;
-    const uint64_t v = i < n ? sizes[i] : 0;
-    uint64_t x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-      uint64_t y = __shfl_up(x, d, 64);
-      if (lane >= (uint32_t)d) x += y;
+  if (t == 0) offsets[0] = base;
+  uint64_t carry = base;  // (every thread keeps it: the pass total is read by all)
+  uint32_t par = 0;
+  for (uint64_t c = 0; c < n; c += (uint64_t)kScanThreads * kPer, par ^= 1) {
+    const uint64_t i0 = c + (uint64_t)t * kPer;
+    uint32_t v[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) v[k] = i0 + k < n ? sizes[i0 + k] : 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kPer; k++) v[k] += v[k - 1];  // (a pass sums at most 8 192 sizes of < 2^17: no overflow)
+    uint32_t wtot;
+    const uint32_t before_t = wave_excl_scan(v[kPer - 1], lane, &wtot);
+    if (lane == 0) s_wave[par][wv] = wtot;
+    __syncthreads();  // (two buffers: the next pass's store cannot overtake this pass's loads)
+    uint32_t before_w = 0, pass_total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanThreads / 64; k++) {
+      const uint32_t w = s_wave[par][k];
+      before_w += k < wv ? w : 0;
+      pass_total += w;
     }
-    if (lane == 63) s_wave[wv] = x;
-    __syncthreads();
-    uint64_t before = s_carry;
-    for (uint32_t k = 0; k < wv; k++) before += s_wave[k];
-    if (i < n) offsets[i + 1] = before + x;
-    __syncthreads();
-    if (t == kScanThreads - 1) s_carry = before + x;
-    __syncthreads();
+    const uint64_t at = carry + before_w + before_t;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++)
+      if (i0 + k < n) offsets[i0 + k + 1] = at + v[k];
+    carry += pass_total;
   }
 }
 

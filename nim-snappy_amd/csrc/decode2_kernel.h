@@ -165,10 +165,17 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // steps must fit.  A unit with a step wider than that, with more than kRingCatchUps wide steps, or with an
 // output that is not 16-byte aligned is handed to the whole-block instantiation (kNeedsWindow), launched
 // second over the same units.
-template <uint32_t WIN>
+// RCRC (ring only): the unit's masked CRC32C is computed WHILE the ring is flushed -- the column scheme of
+// crc32c_units_kernel (the message right-aligned in rows of 1 KiB, one dword column per thread, one Horner
+// step `s <- Z1024(s ^ dword)` per row): a row is final, and still in the ring, when its bytes are flushed, so
+// threads 256..511 take the rows the flush has just completed, their column registers live across the steps.
+// The framed stream (uncompressFramed, snappy.nim:231) then decodes on the ring kernel too.
+template <uint32_t WIN, bool RCRC = false>
 __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
+  static_assert(RING || !RCRC, "the whole-block instantiation checksums its window at the end");
   constexpr uint32_t kOutSink = WIN;
+  constexpr uint32_t kSlack = RCRC ? 1024 : 0;
   auto wa = [](uint32_t x) -> uint32_t { return RING ? (x & (WIN - 1)) : x; };  // window address of output byte x
   // (the ring window is a static array: its LDS address is then a compile-time constant that folds into the
   // instructions' offset fields -- the dynamic array's base is added to every address with an instruction;
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup];  // list slot of the element covering byte 256 m
   __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
   __shared__ uint32_t s_runbad;                          // the unit is not one literal + copies of one offset
+  __shared__ uint32_t s_rcrc_tab[RCRC ? 1024 : 1];       // (ring + CRC) the four stride tables of the column scheme
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -477,8 +485,10 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       const uint32_t hi = s_sbase[tid + 1 <= n_chunks ? tid + 1 : n_chunks];
       const uint32_t lo = tid >= 1 ? s_sbase[tid - 1] & ~15u : 0;
       const uint32_t lo3 = tid >= 2 ? s_sbase[tid - 2] & ~15u : 0;
-      wide = wide || hi - lo > WIN;
-      catch_up = hi - lo3 > WIN;
+      // (RCRC: a row that the flush completes starts up to 1 023 bytes below the previous step's flush
+      // mark, and must still be in the ring: a KiB of slack in every ring condition)
+      wide = wide || hi + kSlack - lo > WIN;
+      catch_up = hi + kSlack - lo3 > WIN;
     }
     const uint32_t n_catch = __syncthreads_count(catch_up);
     if (__syncthreads_or(wide) || n_catch > kRingCatchUps) {
@@ -486,6 +496,47 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       return;
     }
   }
+  // ---- (ring + CRC) the column scheme's state: rows of 1 KiB of the right-aligned message ----------------
+  const bool do_crc = RCRC && prm.crc != nullptr && total >= 4;  // (shorter units: the CRC kernel, crc_done stays 0)
+  const uint32_t crc_rows_n = (total + 1023) / 1024;
+  const uint32_t crc_pad = crc_rows_n * 1024 - total;  // virtual zero bytes in front of the message
+  uint32_t crc_row = 0;   // rows done (uniform)
+  uint32_t crc_reg = 0;   // my column's register (threads 256..511: column tid - 256)
+  if (do_crc) {
+    for (uint32_t i = tid; i < 1024; i += kD2Threads) s_rcrc_tab[i] = prm.crc_tab[i];
+    // (visible to waves 4-7 after the next barrier; the first rows are taken in step 1 at the earliest)
+  }
+  // rows that end at or below `to` (a position everything below which is final and still in the ring)
+  auto crc_rows_to = [&](uint32_t to) {
+    const uint32_t upto_row = (to + crc_pad) / 1024;  // rows [crc_row, upto_row) are complete
+    if (tid >= 256) {
+      const uint32_t t = tid - 256;
+      const uint32_t sh8 = (total & 3) * 8;  // byte phase of the columns' dwords (0 for whole blocks)
+      const uint32_t* const o32 = reinterpret_cast<const uint32_t*>(s_out);
+      for (uint32_t r = crc_row; r < upto_row; r++) {
+        const int32_t pos = (int32_t)(r * 1024 + 4 * t) - (int32_t)crc_pad;
+        uint32_t w;
+        if (pos >= 4) {  // aligned dwords + funnel shift; the two may lie on both sides of the ring's end
+          const uint32_t a = (uint32_t)pos & ~3u;
+          w = __funnelshift_r(o32[wa(a) >> 2], o32[wa(a + 4) >> 2], sh8);
+        } else {  // the message's start: virtual zero padding in front of it, the 0xffffffff init on its first 4 bytes
+          w = 0;
+          for (int k = 0; k < 4; k++) {
+            const int32_t j = pos + k;
+            if (j >= 0) w |= (uint32_t)(s_out[wa((uint32_t)j)] ^ (j < 4 ? 0xff : 0)) << (8 * k);
+          }
+        }
+        const uint32_t x = crc_reg ^ w;
+        if (r + 1 < crc_rows_n) {
+          crc_reg = s_rcrc_tab[x & 0xff] ^ s_rcrc_tab[256 + ((x >> 8) & 0xff)] ^ s_rcrc_tab[512 + ((x >> 16) & 0xff)] ^
+                    s_rcrc_tab[768 + (x >> 24)];
+        } else {
+          crc_reg = gf2_mulmod(prm.crc_col[t], x);  // the 4 * (256 - t) bytes from here to the message's end
+        }
+      }
+    }
+    crc_row = upto_row > crc_row ? upto_row : crc_row;
+  };
   bool passed_on = false;
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
@@ -521,20 +572,22 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
           *reinterpret_cast<uint4*>(gout + i) = *reinterpret_cast<const uint4*>(s_out + wa(i));
         flushed = to > flushed ? to : flushed;
       };
-      if (hi - far_lo > WIN) {
+      if (hi + kSlack - far_lo > WIN) {
         // a wide step (a stretch of copies: much output from little stream): what is final now is written
         // and waited for at once, so that the ring has to hold two steps only -- a wait for the stores
         // and a barrier, paid by the steps that produce many bytes
         flush_to(upto);
+        if (do_crc) crc_rows_to(upto);  // (before the barrier: the front end may overwrite these bytes after it)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         far_lo = flushed;
-        if (hi - far_lo > WIN) {  // (after a fast-forward the steps are not consecutive: the check before the loop missed it)
+        if (hi + kSlack - far_lo > WIN) {  // (after a fast-forward the steps are not consecutive: the check before the loop missed it)
           passed_on = true;
           break;
         }
       }
       ring_lo = hi > WIN ? hi - WIN : 0;  // (nothing this step writes lies at or beyond hi)
       flush_to(upto);
+      if (do_crc) crc_rows_to(upto);  // (these rows stay in the ring for the whole step: upto >= far_lo >= ring_lo)
     }
     // ---- prefetch hand-over (all waves, straight-line) ---------------------------------------------
     // everything fetched during the previous step is consumed here, BEFORE new loads are issued
@@ -880,6 +933,37 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         const uint32_t expect = g > cb ? g : cb;
         // (from here to the publish this wave is, or is about to be, on the step's critical path)
         __builtin_amdgcn_s_setprio(3);
+#ifndef D2_LOOSE_POLL
+        // (the wait is written out: read, wait, compare -- five instructions a poll; the compiler's form of the
+        // loop below took eighteen scalar instructions a poll, and the scalar unit is shared by the CU's waves)
+        for (uint32_t spin = 0; front < expect; spin += 1024) {
+          uint32_t left = 1024, fv;
+          const uint32_t fa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_front;
+          asm volatile(
+              "1:\n"
+              "ds_read_b32 %[fv], %[fa]\n"
+              "s_waitcnt lgkmcnt(0)\n"
+              "v_readfirstlane_b32 %[fr], %[fv]\n"
+              "s_cmp_ge_u32 %[fr], %[ex]\n"
+              "s_cbranch_scc1 2f\n"
+              "s_sub_u32 %[left], %[left], 1\n"
+              "s_cmp_lg_u32 %[left], 0\n"
+              "s_cbranch_scc1 1b\n"
+              "2:\n"
+              : [fr] "+s"(front), [fv] "=&v"(fv), [left] "+s"(left)
+              : [fa] "v"(fa), [ex] "s"(expect)
+              : "scc", "memory");
+          if (front >= expect) break;
+          if (spin > 400000 || s_err != 0) {
+            // cannot happen on a consistent index; never hang the GPU
+            if (lane == 0) {
+              atomicOr(&s_err, 4u);
+              if (spin > 400000 && prm.timeouts) atomicAdd(prm.timeouts, 1u);
+            }
+            break;
+          }
+        }
+#else
         for (uint32_t spin = 0; front < expect; spin++) {
           if ((spin & 1023) == 1023 && (spin > 400000 || s_err != 0)) {
             // cannot happen on a consistent index; never hang the GPU
@@ -892,6 +976,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
           front = readfirst(__hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           cbar();
         }
+#endif
         if (front > expect) {  // covered by a run extension meanwhile
           __builtin_amdgcn_s_setprio(0);
           continue;
@@ -976,7 +1061,21 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         for (uint32_t k = i; k < total; k++) gout[k] = s_out[wa(k)];
       }
     }
-    return;  // (no CRC from a ring: crc_done stays 0)
+    if (do_crc) {  // the rows the loop has not seen, then the columns together (crc_pack_kernels.h)
+      crc_rows_to(total);
+      uint32_t part = tid >= 256 ? crc_reg : 0;
+      for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
+      if (lane == 0 && wave >= 4) {
+        atomicXor(&s_crc_acc, part);
+        cbar();
+        if (atomicAdd(&s_crc_cnt, 1u) == 3) {  // the last of the four waves: every part is in
+          const uint32_t crc = ~atomicOr(&s_crc_acc, 0u);         // crc32c.c:761
+          prm.crc[u] = ((crc >> 15) | (crc << 17)) + kMaskDelta;    // crc32c.c:762
+          prm.crc_done[u] = 1;
+        }
+      }
+    }
+    return;  // (without RCRC no CRC from a ring: crc_done stays 0)
   }
   if (SNAPPY_DBG(prm) & 8) return;
   if (((uintptr_t)gout & 15) == 0) {

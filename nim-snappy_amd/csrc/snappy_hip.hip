@@ -591,13 +591,17 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       fprintf(stderr, "index verify: %d units with a mismatch\n", shown);
       (void)hipFree(d_rep);
     }
-    // Without the fused CRC (which needs the whole block in the window): the ring-window instantiation,
-    // three workgroups per CU; then the whole-block one over the units it passed on (a workgroup of any
-    // other unit leaves at once).  kD2RingFirst == 0 / SNAPPY_HIP_NO_RING (debug builds): whole-block only.
-    const bool ring_first = kD2RingFirst && dp.crc == nullptr && !dbg_env("SNAPPY_HIP_NO_RING");
+    // The ring-window instantiation first, three workgroups per CU (with the CRC wanted: the variant that
+    // checksums the rows its flush completes); then the whole-block one over the units it passed on (a
+    // workgroup of any other unit leaves at once).  kD2RingFirst == 0 / SNAPPY_HIP_NO_RING (debug builds):
+    // whole-block only.
+    const bool ring_first = kD2RingFirst && !dbg_env("SNAPPY_HIP_NO_RING");
     if (ring_first) {
       LaunchTimer lt(c, s, 0);
-            LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
+      if (dp.crc)  // (the CRC out of the ring's flush: the framed stream's chunks, snappy.nim:231)
+        LAUNCH((decode_indexed_kernel<kRingWin, true>), dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+      else
+        LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
     }
     if (ring_first) {  // the units it passed on, as a list
       void* d_pass;

@@ -4,6 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cmd=$1; shift
 cp $R/nim-snappy_amd/libsnappy_hip.so /tmp/lib_keep.so
+trap 'cp /tmp/lib_keep.so $R/nim-snappy_amd/libsnappy_hip.so' EXIT INT TERM  # the tracked path gets its library back, whatever happens
 for rep in 1 2; do
 for v in "$@"; do
   cp $R/tools/probes/lib_$v.so $R/nim-snappy_amd/libsnappy_hip.so

@@ -74,7 +74,7 @@ def _match_len(data, a, b, n):
     return k
 
 
-def encode_block(data, stats=None):
+def encode_block(data, stats=None, wide=None):
     data = bytes(data)
     n = len(data)
     out = bytearray()
@@ -97,6 +97,16 @@ def encode_block(data, stats=None):
     rounds = dense_rounds = 0
     while tail_from is None:
         rounds += 1
+        if idx0 == 0 and has0 and wide is not None:
+            # encode2_kernel.h: a WIDE round (tools/encode2_model.py) takes this place when it can
+            r = wide(table, hsh, s0 - 2, ip_limit, out)
+            if r is not None:
+                ended, tf, nstate = r
+                if ended:
+                    tail_from = tf
+                else:
+                    has0, s0, idx0, next_emit = nstate
+                continue
         if idx0 == 0:
             dense_rounds += 1
             base = s0 - 2 if has0 else 0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect SQ counters for the encode kernel on one corpus class (run ON the GPU box via gpurun).
-# usage: tools/pmc_decode.sh <class> <tag> [n_blocks]
+# usage: tools/pmc_encode.sh <class> <tag> [n_blocks]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CLS=${1:-T_TEXT}; TAG=${2:-pmc}; NB=${3:-4096}
 cd /tmp && export TMPDIR=/tmp
