@@ -22,6 +22,13 @@
  * context (snappy_hip_ctx_create) serves one thread (and one stream) at a time: it owns scratch
  * buffers that its calls reuse.  Every entry point makes its context's device current for the
  * call and restores the caller's.
+ *
+ * Environment (read once, by the host-buffer calls only; the device-resident API reads none):
+ *   SNAPPY_HIP_DEVICE        GPU of the pooled contexts (default 0)
+ *   SNAPPY_HIP_HOST_BATCH    blocks per upload/compute/download batch (64 .. 65536, default 2048)
+ *   SNAPPY_HIP_PIN_HOST      0 pageable copies (default) / 1, 2 page-lock the caller's buffers per call, per batch
+ *                            (hipHostRegister on the caller's memory) / 3, 4 the contexts' page-locked staging rings
+ *   SNAPPY_HIP_COPY_THREADS  host threads of the staging rings' copies (modes 3, 4)
  */
 #ifndef SNAPPY_HIP_H
 #define SNAPPY_HIP_H
@@ -95,6 +102,11 @@ int snappy_hip_decode_all_tags(const uint8_t* in, size_t n, uint8_t* out, size_t
  * batches shard across GPUs by block range with no collective. */
 typedef struct snappy_hip_ctx snappy_hip_ctx;
 
+/* The host-buffer calls above run on pooled contexts (created on demand, one per concurrent call; an idle
+ * context keeps its grow-only device workspace, and at most four idle ones are kept).  This frees the idle
+ * ones now -- e.g. after one very large call.  Calls in flight keep theirs. */
+void snappy_hip_release_pool(void);
+
 int snappy_hip_ctx_create(snappy_hip_ctx** ctx, int device);
 void snappy_hip_ctx_destroy(snappy_hip_ctx* ctx);
 int snappy_hip_ctx_sync(snappy_hip_ctx* ctx, void* stream);
@@ -134,9 +146,9 @@ int snappy_hip_decode_blocks_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const u
 int snappy_hip_crc32c_d(snappy_hip_ctx* ctx, const uint8_t* d_in, const uint64_t* d_off,
                         const uint32_t* d_len, uint64_t n_units, uint32_t* d_crc, void* stream);
 /* uncompress, snappy.nim:84-110, of ONE raw buffer RESIDENT IN HBM (the varint and all) into d_out.
- * A buffer of several 64 KiB blocks is split on the device and its blocks are decoded in parallel;
- * streams whose elements straddle block boundaries (foreign encoders) take the serial kernel.
- * *written is host memory; returns when done. */
+ * A buffer of several 64 KiB blocks is split on the device and its blocks are decoded in parallel (on
+ * `stream` when one is given); streams whose elements straddle block boundaries (foreign encoders) take
+ * the serial kernel.  *written is host memory; returns when done. */
 int snappy_hip_uncompress_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uint64_t n, uint8_t* d_out,
                             uint64_t cap, uint64_t* written, void* stream);
 /* compressFramed, snappy.nim:130-155, for an input RESIDENT IN HBM: stream identifier + one chunk

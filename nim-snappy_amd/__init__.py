@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
     "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d", "snappy_hip_uncompress_d",
-    "snappy_hip_compress_shards",
+    "snappy_hip_compress_shards", "snappy_hip_release_pool",
 ]
 
 
@@ -101,9 +101,16 @@ lib.snappy_hip_compress_shards.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ct
                                            ctypes.POINTER(ctypes.c_uint64)]
 lib.snappy_hip_uncompress_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), _vp]
+lib.snappy_hip_release_pool.restype = None
+lib.snappy_hip_release_pool.argtypes = []
 lib.snappy_hip_ctx_timing.argtypes = [_vp, ctypes.c_int]
 lib.snappy_hip_ctx_kernel_ms.restype = ctypes.c_double
 lib.snappy_hip_ctx_kernel_ms.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+
+
+def release_pool():
+    """Frees the idle pooled contexts of the host-buffer calls (their device workspace)."""
+    lib.snappy_hip_release_pool()
 
 
 def last_error():

@@ -35,6 +35,11 @@ struct CrcParams {
   uint64_t total_len;
   uint32_t block_len;
   const uint8_t* done;  // != nullptr: units with done[u] != 0 already have their CRC (decode2_kernel.h)
+  // != nullptr: the bytes are also COPIED while they are read, unit u to copy_out + copy_off[u] when copy_cap[u]
+  // != 0 (a stored chunk of a framed stream: checksummed and delivered in one pass, snappy.nim:244-256)
+  uint8_t* copy_out;
+  const uint64_t* copy_off;
+  const uint32_t* copy_cap;
 };
 
 // a(x)*b(x) mod P(x), reflected representation (bit 31 = x^0).
@@ -77,18 +82,28 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
       reg ^= msg[i];
       for (int k = 0; k < 8; k++) reg = (reg >> 1) ^ ((reg & 1) ? kCrcPoly : 0);
     }
+    if (t == 0 && prm.copy_out && prm.copy_cap[u])
+      for (uint32_t i = 0; i < n; i++) prm.copy_out[prm.copy_off[u] + i] = msg[i];
   } else {
     const uint32_t row_bytes = 4 * kCrcThreads;
     const uint32_t rows = (n + row_bytes - 1) / row_bytes;
     const int64_t pad = (int64_t)rows * row_bytes - n;  // virtual leading zero bytes
     uint32_t s = 0;
+    uint8_t* const cp = (prm.copy_out && prm.copy_cap[u]) ? prm.copy_out + prm.copy_off[u] : nullptr;
     auto word = [&](uint32_t r) -> uint32_t {  // my dword of row r
       const int64_t pos = (int64_t)r * row_bytes + 4 * t - pad;
-      if (pos >= 4) return ld32u(msg + pos);
+      if (pos >= 4) {
+        const uint32_t w = ld32u(msg + pos);
+        if (cp) st32u(cp + pos, w);
+        return w;
+      }
       uint32_t w = 0;  // touches the message start: virtual zero padding and the 0xffffffff init
       for (int k = 0; k < 4; k++) {
         const int64_t j = pos + k;
-        if (j >= 0) w |= (uint32_t)(msg[j] ^ (j < 4 ? 0xff : 0)) << (8 * k);
+        if (j >= 0) {
+          w |= (uint32_t)(msg[j] ^ (j < 4 ? 0xff : 0)) << (8 * k);
+          if (cp) cp[j] = msg[j];
+        }
       }
       return w;
     };

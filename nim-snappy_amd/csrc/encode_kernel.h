@@ -517,6 +517,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       // the copy-loop probe may sit at ip = n - 15: findMatchLength stops at the block's end
       eq = eq < n - p ? eq : n - p;
     }
+    // (Measuring matches that fill the 16 bytes on by their own lanes -- 64 more bytes, every such lane of the
+    // round at once -- was built and measured: the second trip to the L2 costs a round more than the chain's
+    // one-by-one extensions cost it: text +6 %, html +9 % time.  profiles/README.md)
+    constexpr uint32_t eqcap = 16;  // what a lane has looked at: a match of that length may be longer
     tick(3);  // wait for the candidates + compare
 
     if (fresh) {
@@ -540,52 +544,67 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         // then two register reads per copy.
         const uint64_t cnd = mine & m4;
         const uint32_t mv = cnd ? ctz64(cnd) : 64;
-        const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)eq);
-        // 255: nothing found; 128 + m: the match at m is longer than the 16 bytes in registers
-        const uint32_t nxt = mv == 64 ? 255u : (lm == 16 ? 128u + mv : mv + lm);
+        const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)(eq | (eq == eqcap ? 0x100u : 0u)));
+        // 255: nothing found; 254: the match at mv may be longer than what its lane has looked at; else the lane
+        // where the copy ends (< 63 inside the round, up to 63 + 79 behind it)
+        const uint32_t nxt = mv == 64 ? 255u : ((lm & 0x100u) ? 254u : mv + lm);
         const uint32_t pk = nxt | (mv << 8);
+        // ... and two copies per trip of the loop: next to a lane's own hop the hop of the lane it leads to
+        // (one more ds_bpermute here; the loop then pays its register read across lanes and its taken branch once
+        // per two copies)
+        const uint32_t pk2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nxt & 63) << 2), (int)pk);
+        const uint32_t P = pk | (pk2 << 16);
         tick(4);  // chain: per-lane preparation
         uint64_t E = 0;  // ends of copies from which the chain went on
-        uint32_t x = readlane(pk, e);
-        uint32_t t = x & 255;
+        uint32_t x = readlane(P, e);
+        uint32_t t, m;
         for (;;) {
-          if (t < 63) {
-            // the copy found from e ends inside the round at t: note e and the match, go to t.
-            // (A taken branch costs a lone wave about 25 cycles, a register read across lanes as
-            // much, a scalar instruction 5: this loop is written out so that a copy costs one of
-            // each and eight scalar instructions.)
+          // Hops that stay inside the round (the copy found from e ends at t < 63): note e and the match, go to
+          // t.  Leaves with (e, t, m) = the first hop that does not: nothing found (255), a match that may be
+          // longer than its lane has looked (254), a copy that ends behind the round (63 ..).  (A taken branch costs a
+          // lone wave about 25 cycles, a register read across lanes as much, a scalar instruction 5.)
+          {
             uint64_t tmp;
-            uint32_t m;
             asm volatile(
                 "1:\n"
+                "s_and_b32 %[t], %[x], 0xff\n"
+                "s_bfe_u32 %[m], %[x], 0x80008\n"
+                "s_cmp_lt_u32 %[t], 63\n"
+                "s_cbranch_scc0 2f\n"
                 "s_lshl_b64 %[tmp], 1, %[e]\n"
                 "s_or_b64 %[E], %[E], %[tmp]\n"
-                "s_lshr_b32 %[m], %[x], 8\n"
                 "s_lshl_b64 %[tmp], 1, %[m]\n"
                 "s_or_b64 %[MS], %[MS], %[tmp]\n"
                 "s_mov_b32 %[e], %[t]\n"
-                "v_readlane_b32 %[x], %[pk], %[e]\n"
-                "s_and_b32 %[t], %[x], 0xff\n"
+                "s_bfe_u32 %[t], %[x], 0x80010\n"
+                "s_lshr_b32 %[m], %[x], 24\n"
                 "s_cmp_lt_u32 %[t], 63\n"
-                "s_cbranch_scc1 1b\n"
-                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "+s"(t), [x] "+s"(x), [tmp] "=&s"(tmp), [m] "=&s"(m)
-                : [pk] "v"(pk)
+                "s_cbranch_scc0 2f\n"
+                "s_lshl_b64 %[tmp], 1, %[e]\n"
+                "s_or_b64 %[E], %[E], %[tmp]\n"
+                "s_lshl_b64 %[tmp], 1, %[m]\n"
+                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_mov_b32 %[e], %[t]\n"
+                "v_readlane_b32 %[x], %[P], %[e]\n"
+                "s_branch 1b\n"
+                "2:\n"
+                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x), [tmp] "=&s"(tmp)
+                : [P] "v"(P)
                 : "scc");
           }
           if (t == 255) break;  // nothing found from e: the round ends there
           E |= 1ull << e;
-          const uint32_t m = x >> 8;
           MS |= 1ull << m;
-          if (t >= 128) {       // found, and longer than the registers show
-            const uint32_t matched = 16 + extend_match(readlane(cand, m) + 16, base + m + 16);
+          if (t == 254) {       // found, and it may go on behind what its lane has looked at
+            const uint32_t seen = readlane(eq, m);
+            const uint32_t matched = seen + extend_match(readlane(cand, m) + seen, base + m + seen);
             lens = lane == m ? matched : lens;
             e = m + matched;
           } else {              // found, and it ends behind the round
             e = t;
           }
           if (e > 62) break;
-          x = readlane(pk, e);
-          t = x & 255;
+          x = readlane(P, e);
         }
         tick(5);  // chain: hops
         if (MS) {
@@ -683,7 +702,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           // a match at lane m: literal up to it (if any) + copy (encoder.nim:336-359)
           S |= opA | opB | (VS & ((2ull << m) - 1));
           uint32_t matched = readlane(eq, m);
-          if (matched == 16 && base + m + 16 < n) matched += extend_match(readlane(cand, m) + 16, base + m + 16);
+          if (matched == eqcap && base + m + matched < n)
+            matched += extend_match(readlane(cand, m) + matched, base + m + matched);
           MS |= 1ull << m;
           lens = lane == m ? matched : lens;
           COVER |= (matched >= 64 ? ~0ull : ((1ull << matched) - 1)) << m;

@@ -38,6 +38,7 @@ struct FrameScanResult {
   uint64_t stop_rd, stop_wr;
   uint64_t walk_rd;           // where the walk ended
   uint64_t deliver;           // output bytes assigned to chunks
+  uint32_t need_comp, need_stored;  // list entries the walk needs (it goes on counting behind a full list)
 };
 
 struct FrameScanParams {
@@ -136,18 +137,18 @@ __global__ __launch_bounds__(64) void frame_scan_kernel(FrameScanParams p) {
         }
         break;
       }
-      if (r.n_comp >= p.list_cap) {
-        r.overflow = 1;
-        break;
+      const uint32_t k = r.need_comp++;
+      if (k < p.list_cap) {
+        p.comp.in_off[k] = rd + 4;
+        p.comp.in_len[k] = (uint32_t)(data_len - 4);
+        p.comp.out_off[k] = wr;
+        p.comp.out_cap[k] = (uint32_t)ulen;
+        p.comp.crc[k] = w[1];
+        p.comp.seq[k] = seq++;
+        p.comp.hdr_at[k] = hdr_at;
+      } else {
+        r.overflow = 1;  // (the walk goes on, counting: the next attempt sizes the lists exactly)
       }
-      const uint32_t k = r.n_comp++;
-      p.comp.in_off[k] = rd + 4;
-      p.comp.in_len[k] = (uint32_t)(data_len - 4);
-      p.comp.out_off[k] = wr;
-      p.comp.out_cap[k] = (uint32_t)ulen;
-      p.comp.crc[k] = w[1];
-      p.comp.seq[k] = seq++;
-      p.comp.hdr_at[k] = hdr_at;
       wr += ulen;
     } else if (id == 0x01) {  // snappy.nim:237-257
       if (data_len < 4) {
@@ -155,22 +156,22 @@ __global__ __launch_bounds__(64) void frame_scan_kernel(FrameScanParams p) {
         break;
       }
       const uint64_t ul = data_len - 4;
-      if (r.n_stored >= p.list_cap) {
-        r.overflow = 1;
-        break;
-      }
       // the reference verifies the CRC BEFORE the size checks (snappy.nim:244-254)
       if (ul > kMaxBlockLen || ul > p.cap - wr) {
         const int32_t after = ul > kMaxBlockLen ? (int32_t)kInvalidInput : -2;  // -2: output full
         if (p.check_integrity) {  // checksum it without delivering it; it ends the walk
-          const uint32_t k = r.n_stored++;
-          p.stored.in_off[k] = rd + 4;
-          p.stored.in_len[k] = (uint32_t)ul;
-          p.stored.out_off[k] = wr;  // (nothing is delivered: out_cap 0)
-          p.stored.out_cap[k] = 0;
-          p.stored.crc[k] = w[1];
-          p.stored.seq[k] = seq++;
-          p.stored.hdr_at[k] = hdr_at;
+          const uint32_t k = r.need_stored++;
+          if (k < p.list_cap) {
+            p.stored.in_off[k] = rd + 4;
+            p.stored.in_len[k] = (uint32_t)ul;
+            p.stored.out_off[k] = wr;  // (nothing is delivered: out_cap 0)
+            p.stored.out_cap[k] = 0;
+            p.stored.crc[k] = w[1];
+            p.stored.seq[k] = seq++;
+            p.stored.hdr_at[k] = hdr_at;
+          } else {
+            r.overflow = 1;
+          }
           r.tail_after = after;
         } else if (after == -2) {
           r.stop_ok = 1;
@@ -181,14 +182,18 @@ __global__ __launch_bounds__(64) void frame_scan_kernel(FrameScanParams p) {
         }
         break;
       }
-      const uint32_t k = r.n_stored++;
-      p.stored.in_off[k] = rd + 4;
-      p.stored.in_len[k] = (uint32_t)ul;
-      p.stored.out_off[k] = wr;
-      p.stored.out_cap[k] = (uint32_t)ul;
-      p.stored.crc[k] = w[1];
-      p.stored.seq[k] = seq++;
-      p.stored.hdr_at[k] = hdr_at;
+      const uint32_t k = r.need_stored++;
+      if (k < p.list_cap) {
+        p.stored.in_off[k] = rd + 4;
+        p.stored.in_len[k] = (uint32_t)ul;
+        p.stored.out_off[k] = wr;
+        p.stored.out_cap[k] = (uint32_t)ul;
+        p.stored.crc[k] = w[1];
+        p.stored.seq[k] = seq++;
+        p.stored.hdr_at[k] = hdr_at;
+      } else {
+        r.overflow = 1;
+      }
       wr += ul;
     } else if (id < 0x80) {  // snappy.nim:259-260
       r.terminal = (int32_t)kStUnknownChunk;
@@ -199,6 +204,8 @@ __global__ __launch_bounds__(64) void frame_scan_kernel(FrameScanParams p) {
   }
   r.walk_rd = rd;
   r.deliver = wr;
+  r.n_comp = r.need_comp < p.list_cap ? r.need_comp : p.list_cap;
+  r.n_stored = r.need_stored < p.list_cap ? r.need_stored : p.list_cap;
   *p.res = r;
 }
 

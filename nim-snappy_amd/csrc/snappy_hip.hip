@@ -13,6 +13,7 @@
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -120,6 +121,11 @@ struct snappy_hip_ctx {
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
   uint32_t* d_counters = nullptr;  // [16] [0] turns the indexed decoder gave up on (kernel_ms slot 9)
   DevBuf ws[24];                   // grow-only workspace of the host-buffer API
+  // page-locked staging ring of the host-buffer calls (stage_*, below): kStageSlots pieces, an event each
+  uint8_t* stage = nullptr;
+  hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy[4] = {false, false, false, false};
+  bool stage_failed = false;       // the ring could not be allocated: copies go the runtime's pageable way
   bool timing = false;
   struct Timed {
     hipEvent_t a, b;
@@ -286,6 +292,9 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   }
   for (auto& b : c->ws)
     if (b.p) (void)hipFree(b.p);
+  if (c->stage) (void)hipHostFree(c->stage);
+  for (auto& e : c->stage_ev)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_crc_tab);
   (void)hipFree(c->d_col_mul);
   (void)hipFree(c->d_seq_off);
@@ -846,11 +855,15 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       if (dbg_env("SNAPPY_HIP_STATS")) fprintf(stderr, "FRAME WALK fill irregular %u fast_ok %u\n", flags[0], flags[1]);
     }
   }
+  uint64_t need_lists = 0;
   for (int attempt = 0; !have_lists; attempt++) {  // the serial walk: every stream, every verdict
-    // chunk lists: room for one chunk per KiB of stream at first; a stream of tinier chunks (a data
-    // chunk takes at least 8 bytes) gets lists for the worst case on the second attempt
-    const uint64_t want = attempt == 0 ? n / 1024 + 4096 : n / 8 + 16;
-    if (want > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
+    // chunk lists: room for one chunk per KiB of stream at first; a stream of tinier chunks makes the walk
+    // count on behind the full list, and the second attempt's lists are sized by that count
+    const uint64_t want = attempt == 0 ? n / 1024 + 4096 : need_lists + 16;
+    if (want > 0x7fffffffull) {  // (more than 2^31 chunks: a device limit, not a malformed stream)
+      g_last_error = "framed stream of more than 2^31 chunks";
+      return SNAPPY_HIP_DEVICE_ERROR;
+    }
     const size_t cap_l = (size_t)want;
     int st = carve_lists(cap_l);
     if (st) return st;
@@ -872,6 +885,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
     HIP_TRY(hipMemcpyAsync(&res, d_res, sizeof res, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (!res.overflow) break;
+    need_lists = res.need_comp > res.need_stored ? res.need_comp : res.need_stored;
     if (attempt == 1) {
       g_last_error = "internal: chunk lists overflowed twice";
       return SNAPPY_HIP_DEVICE_ERROR;
@@ -882,13 +896,25 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
                       comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr);
     if (st) return st;
   }
-  if (res.n_stored) {  // stored chunks: checksum the payload (snappy.nim:244), then copy it (:256)
-    if (check_integrity) {
-      int st = snappy_hip_crc32c_d(c, d_in, stored.in_off, stored.in_len, res.n_stored, stored_crc, s);
-      if (st) return st;
+  if (res.n_stored) {  // stored chunks: checksum the payload (snappy.nim:244) and copy it (:256)
+    if (check_integrity) {  // ... in one pass over the bytes
+      CrcParams cp{};
+      cp.in = d_in;
+      cp.off = stored.in_off;
+      cp.len = stored.in_len;
+      cp.crc = stored_crc;
+      cp.n_units = res.n_stored;
+      cp.stride_tab = c->d_crc_tab;
+      cp.col_mul = c->d_col_mul;
+      cp.copy_out = d_out;
+      cp.copy_off = stored.out_off;
+      cp.copy_cap = stored.out_cap;  // (0 for a chunk that is only checksummed)
+      LaunchTimer lt(c, s, 2);
+      LAUNCH(crc32c_units_kernel, dim3(res.n_stored), dim3(kCrcThreads), 0, s, cp);
+    } else {
+      LAUNCH(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
+                         stored.out_off, d_res, d_out);
     }
-    LAUNCH(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
-                       stored.out_off, d_res, d_out);
     HIP_TRY(hipGetLastError());
   }
   FrameVerdictParams vp{};
@@ -924,6 +950,9 @@ extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, co
                                           uint64_t* written, uint64_t* shard_off) {
   *written = 0;
   if (n <= 0) return SNAPPY_HIP_INVALID_INPUT;
+  for (int k = 0; k < n; k++)  // a context serves one shard at a time (it owns the scratch buffers its calls use)
+    for (int j = 0; j < k; j++)
+      if (ctxs[j] == ctxs[k] || !ctxs[k]) return SNAPPY_HIP_INVALID_INPUT;
   uint64_t total_in = 0;
   for (int k = 0; k < n; k++) {
     if (k + 1 < n && in_len[k] % kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // shards are whole blocks
@@ -976,12 +1005,22 @@ extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, co
     totals[k] = end;
     packed[k] = d_out;
   };
-  {
+  // (one thread per shard; a shard whose thread cannot be had runs on this one: nothing crosses the C boundary)
+  auto fan_out = [&](auto&& phase) {
     std::vector<std::thread> th;
-    for (int k = 1; k < n; k++) th.emplace_back(phase1, k);
-    phase1(0);
+    std::vector<int> inline_k;
+    for (int k = 1; k < n; k++) {
+      try {
+        th.emplace_back(phase, k);
+      } catch (...) {
+        inline_k.push_back(k);
+      }
+    }
+    phase(0);
+    for (int k : inline_k) phase(k);
     for (auto& t : th) t.join();
-  }
+  };
+  fan_out(phase1);
   for (int k = 0; k < n; k++)
     if (status[k]) {
       g_last_error = errs[k];
@@ -1001,12 +1040,7 @@ extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, co
         hipStreamSynchronize(c->stream) != hipSuccess)
       status[k] = SNAPPY_HIP_DEVICE_ERROR;
   };
-  {
-    std::vector<std::thread> th;
-    for (int k = 1; k < n; k++) th.emplace_back(phase2, k);
-    phase2(0);
-    for (auto& t : th) t.join();
-  }
+  fan_out(phase2);
   for (int k = 0; k < n; k++)
     if (status[k]) return status[k];
   if (shard_off)
@@ -1077,6 +1111,7 @@ namespace {
 // largest number of calls that ever ran at once.  (SNAPPY_HIP_DEVICE picks the GPU.)
 std::mutex g_pool_mu;
 std::vector<snappy_hip_ctx*> g_pool;
+constexpr size_t kPoolKeep = 4;  // idle contexts kept (a large call uses three at once)
 
 struct CtxLease {
   snappy_hip_ctx* c = nullptr;
@@ -1100,8 +1135,15 @@ struct CtxLease {
   ~CtxLease() {
     delete guard;
     if (c) {
-      std::lock_guard<std::mutex> lk(g_pool_mu);
-      g_pool.push_back(c);
+      // an idle context keeps its (grow-only) workspace: the pool keeps at most kPoolKeep of them, the rest
+      // give their memory back (snappy_hip_release_pool() frees the idle ones at any time)
+      bool keep;
+      {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        keep = g_pool.size() < kPoolKeep;
+        if (keep) g_pool.push_back(c);
+      }
+      if (!keep) snappy_hip_ctx_destroy(c);
     }
   }
   CtxLease(const CtxLease&) = delete;
@@ -1117,8 +1159,9 @@ struct CtxLease {
 // 5 ms).  If the range cannot be registered (it already is, for instance) copies fall back to the
 // runtime's pageable path.
 constexpr size_t kPinMin = 1u << 20;
-// SNAPPY_HIP_PIN_HOST (read once): 0 = never, pageable copies (default: measured fastest, see
-// INTEGRATION.md), 1 = page-lock the caller's whole buffers for the call, 2 = batch by batch.
+// SNAPPY_HIP_PIN_HOST (read once): 0 = the runtime's pageable copies (default: measured fastest, INTEGRATION.md
+// 6), 1 = page-lock the caller's whole buffers for the call, 2 = batch by batch, 3 = every bulk copy through the
+// contexts' page-locked staging rings (stage_* below), 4 = only the smaller direction of a call through the ring.
 inline int pin_mode() {
   static const int mode = [] {
     const char* e = getenv("SNAPPY_HIP_PIN_HOST");
@@ -1140,6 +1183,175 @@ struct HostPin {
   HostPin(const HostPin&) = delete;
   HostPin& operator=(const HostPin&) = delete;
 };
+
+// ---- page-locked staging of the bulk copies (SNAPPY_HIP_PIN_HOST = 3 / 4; NOT the default) ----------------
+// Every pooled context can own a ring of kStageSlots page-locked pieces, allocated once: an upload is "host
+// threads copy a piece into the ring, the DMA engine takes it from there", piece after piece, the copy of piece
+// k + 1 running beside the transfer of piece k; a download the same the other way round.  Measured (round 3,
+// 1 GiB): the runtime's pageable path moves 56 GB/s one way on this box (its own staging), a
+// host thread copies 14 GB/s, and the ring -- whole (3) or for the smaller direction only (4) -- is slower than
+// or equal to the pageable calls for every entry point but compress() (+9 %): it stays an option, off by default.
+constexpr size_t kStagePiece = 16u << 20;
+constexpr int kStageSlots = 4;
+constexpr size_t kStageMin = 1u << 20;  // smaller copies: the direct call (latency, not bandwidth, matters there)
+
+class CopyPool {  // parallel memcpy; the threads live as long as the process (never joined: no static destructor)
+ public:
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool();
+    return *p;
+  }
+  void copy(void* dst, const void* src, size_t n) {
+    constexpr size_t kGrain = 2u << 20;
+    if (n < 2 * kGrain || n_threads_ == 0) {
+      memcpy(dst, src, n);
+      return;
+    }
+    size_t parts = n / kGrain;
+    if (parts > (size_t)n_threads_ + 1) parts = (size_t)n_threads_ + 1;
+    const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+    Job job;
+    job.left = (int)parts - 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t k = 1; k < parts; k++) {
+        const size_t lo = k * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) {
+          job.left--;
+          continue;
+        }
+        q_.push_back({(uint8_t*)dst + lo, (const uint8_t*)src + lo, hi - lo, &job});
+      }
+    }
+    cv_.notify_all();
+    memcpy(dst, src, per < n ? per : n);
+    std::unique_lock<std::mutex> lk(mu_);
+    job.cv.wait(lk, [&] { return job.left <= 0; });
+  }
+
+ private:
+  struct Job {
+    int left = 0;
+    std::condition_variable cv;
+  };
+  struct Task {
+    uint8_t* d;
+    const uint8_t* s;
+    size_t n;
+    Job* job;
+  };
+  CopyPool() {
+    unsigned hw = std::thread::hardware_concurrency();
+    n_threads_ = hw >= 16 ? 7 : (hw >= 4 ? (int)hw / 2 - 1 : 0);
+    if (const char* e = getenv("SNAPPY_HIP_COPY_THREADS")) n_threads_ = atoi(e) > 0 ? atoi(e) - 1 : 0;
+    for (int i = 0; i < n_threads_; i++) {
+      try {
+        std::thread([this] { run(); }).detach();
+      } catch (...) {
+        n_threads_ = i;
+        break;
+      }
+    }
+  }
+  void run() {
+    for (;;) {
+      Task t;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !q_.empty(); });
+        t = q_.front();
+        q_.pop_front();
+      }
+      memcpy(t.d, t.s, t.n);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--t.job->left <= 0) t.job->cv.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Task> q_;
+  int n_threads_ = 0;
+};
+
+// SNAPPY_HIP_PIN_HOST = 3 (default): the staging ring.  (0: the runtime's pageable copies; 1, 2: page-lock the
+// caller's buffers, see HostPin.)
+inline bool stage_ready(snappy_hip_ctx* c, bool small_side) {
+  // 3: every bulk copy through the ring; 4: only the smaller direction of a call (the compressed side), the
+  // larger one stays with the runtime's pageable path -- the two then run side by side, which two pageable
+  // copies do not
+  if (!(pin_mode() == 3 || (pin_mode() == 4 && small_side)) || c->stage_failed) return false;
+  if (c->stage) return true;
+  if (hipHostMalloc((void**)&c->stage, kStagePiece * kStageSlots, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    c->stage = nullptr;
+    c->stage_failed = true;
+    return false;
+  }
+  for (auto& e : c->stage_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      c->stage_failed = true;
+      return false;
+    }
+  return true;
+}
+
+inline int stage_wait(snappy_hip_ctx* c, int slot) {  // the ring piece is free again
+  if (c->stage_busy[slot]) {
+    HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+    c->stage_busy[slot] = false;
+  }
+  return SNAPPY_HIP_OK;
+}
+
+// d_dst[0 .. n) = src[0 .. n) (host, pageable), enqueued on s: returns when the last piece is in the ring (its
+// transfer may still be under way; what is launched on s afterwards is ordered behind it).
+int stage_upload(snappy_hip_ctx* c, void* d_dst, const uint8_t* src, size_t n, hipStream_t s, bool small_side) {
+  if (n < kStageMin || !stage_ready(c, small_side)) {
+    HIP_TRY(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, s));
+    return SNAPPY_HIP_OK;
+  }
+  int slot = 0;
+  for (size_t off = 0; off < n; off += kStagePiece, slot = (slot + 1) % kStageSlots) {
+    const size_t len = n - off < kStagePiece ? n - off : kStagePiece;
+    int st = stage_wait(c, slot);
+    if (st) return st;
+    uint8_t* piece = c->stage + (size_t)slot * kStagePiece;
+    CopyPool::get().copy(piece, src + off, len);
+    HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + off, piece, len, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->stage_ev[slot], s));
+    c->stage_busy[slot] = true;
+  }
+  return SNAPPY_HIP_OK;
+}
+
+// dst[0 .. n) (host, pageable) = d_src[0 .. n), behind what is enqueued on s; returns when the bytes are there.
+int stage_download(snappy_hip_ctx* c, uint8_t* dst, const void* d_src, size_t n, hipStream_t s, bool small_side) {
+  if (n < kStageMin || !stage_ready(c, small_side)) {
+    HIP_TRY(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SNAPPY_HIP_OK;
+  }
+  const size_t pieces = (n + kStagePiece - 1) / kStagePiece;
+  size_t issued = 0;
+  for (size_t done = 0; done < pieces; done++) {
+    // keep the ring full of transfers, then take the oldest piece out while the others are under way
+    for (; issued < pieces && issued < done + kStageSlots; issued++) {
+      const int slot = (int)(issued % kStageSlots);
+      int st = stage_wait(c, slot);  // (a piece of an earlier upload)
+      if (st) return st;
+      const size_t off = issued * kStagePiece, len = n - off < kStagePiece ? n - off : kStagePiece;
+      HIP_TRY(hipMemcpyAsync(c->stage + (size_t)slot * kStagePiece, (const uint8_t*)d_src + off, len, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(c->stage_ev[slot], s));
+      c->stage_busy[slot] = true;
+    }
+    const int slot = (int)(done % kStageSlots);
+    int st = stage_wait(c, slot);
+    if (st) return st;
+    const size_t off = done * kStagePiece, len = n - off < kStagePiece ? n - off : kStagePiece;
+    CopyPool::get().copy(dst + off, c->stage + (size_t)slot * kStagePiece, len);
+  }
+  return SNAPPY_HIP_OK;
+}
 
 // Runs fn(batch index, context) for every batch: one batch inline, several on up to three worker
 // threads, each with a context of its own -- the upload of one batch, the kernels of another and the
@@ -1163,16 +1375,21 @@ int run_batches(size_t n_batches, snappy_hip_ctx* own, F fn) {
     }
   };
   std::vector<std::thread> threads;
-  for (size_t w = 1; w < n_workers; w++)
-    threads.emplace_back([&, w] {
-      CtxLease lease;
-      if (!lease.c) {
-        int exp = SNAPPY_HIP_OK;
-        if (first_err.compare_exchange_strong(exp, lease.status)) errs[w] = g_last_error;
-        return;
-      }
-      work(w, lease.c);
-    });
+  for (size_t w = 1; w < n_workers; w++) {
+    try {
+      threads.emplace_back([&, w] {
+        CtxLease lease;
+        if (!lease.c) {
+          int exp = SNAPPY_HIP_OK;
+          if (first_err.compare_exchange_strong(exp, lease.status)) errs[w] = g_last_error;
+          return;
+        }
+        work(w, lease.c);
+      });
+    } catch (...) {  // (no thread to be had: the batches go to the workers there are; nothing crosses the C boundary)
+      break;
+    }
+  }
   work(0, own);
   for (auto& t : threads) t.join();
   const int st = first_err.load();
@@ -1228,7 +1445,7 @@ int encode_host(snappy_hip_ctx* own, const uint8_t* in, size_t n, int unit, uint
     if ((st = ws_get(c, 4, cnt * (size_t)kSlotStride + 64, &d_out))) return fail(st);
     hipStream_t s = c->stream;
     HostPin pin_in(in + in_lo, in_n, 2);
-    if (hipMemcpyAsync(d_in, in + in_lo, in_n, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SNAPPY_HIP_DEVICE_ERROR);
+    if ((st = stage_upload(c, d_in, in + in_lo, in_n, s, false))) return fail(st);
     if ((st = snappy_hip_encode_blocks_d(c, (const uint8_t*)d_in, in_n, kMaxBlockLen, unit, (uint8_t*)d_slots,
                                          kSlotStride, (uint32_t*)d_sizes, s)))
       return fail(st);
@@ -1259,9 +1476,7 @@ int encode_host(snappy_hip_ctx* own, const uint8_t* in, size_t n, int unit, uint
       return fail(SNAPPY_HIP_DEVICE_ERROR);
     }
     HostPin pin_out(out + at, (size_t)end, 2);
-    if (hipMemcpyAsync(out + at, d_out, end, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-      return fail(SNAPPY_HIP_DEVICE_ERROR);
+    if ((st = stage_download(c, out + at, d_out, (size_t)end, s, true))) return fail(st);
     return SNAPPY_HIP_OK;
   };
   const int st = run_batches(n_batches, own, fn);
@@ -1326,7 +1541,7 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
   if ((st = ws_get(c, 9, nu, &d_kd))) return st;
   if ((st = ws_get(c, 10, nu * 4, &d_crc))) return st;
   hipStream_t s = c->stream;
-  HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  if ((st = stage_upload(c, d_in, in, n, s, true))) return st;
   HIP_TRY(hipMemcpyAsync(d_io, io.data(), nu * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_il, il.data(), nu * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_oo, oo.data(), nu * 8, hipMemcpyHostToDevice, s));
@@ -1354,7 +1569,7 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
   if (want_crc) HIP_TRY(hipMemcpyAsync(crc->data(), d_crc, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(status->data(), d_st, nu * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_len->data(), d_ol, nu * 4, hipMemcpyDeviceToHost, s));
-  if (copy_bytes) HIP_TRY(hipMemcpyAsync(out, d_out, copy_bytes, hipMemcpyDeviceToHost, s));
+  if (copy_bytes && (st = stage_download(c, out, d_out, copy_bytes, s, false))) return st;
   HIP_TRY(hipStreamSynchronize(s));
   {  // back to the caller's unit order
     std::vector<uint32_t> t(nu);
@@ -1485,7 +1700,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
 // (d_in_res / d_out_res: the buffer / the output are resident in device memory already)
 int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32_t hdr, uint64_t len,
                           uint8_t* out, size_t* written, const uint8_t* d_in_res = nullptr,
-                          uint8_t* d_out_res = nullptr) {
+                          uint8_t* d_out_res = nullptr, hipStream_t on = nullptr) {
   if (len > (1ull << 31) || n >= (1ull << 31)) return -1;  // (positions carry a flag in bit 31: split_kernels.h)
   int st;
   const size_t nblk = (size_t)((len + kMaxBlockLen - 1) / kMaxBlockLen);
@@ -1501,8 +1716,8 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   if ((st = ws_get(c, 8, nblk * 4, &d_st))) return st;
   if ((st = ws_get(c, 9, (nblk + 1) * 4, &d_blk))) return st;
   if ((st = ws_get(c, 10, 64, &d_one))) return st;
-  hipStream_t s = c->stream;
-  if (!d_in_res) HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, s));
+  hipStream_t s = on ? on : c->stream;  // (the device-resident entry point passes the caller's stream on)
+  if (!d_in_res && (st = stage_upload(c, d_in, in, n, s, true))) return st;
   HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
   // first the speculative parallel walk (split_kernels.h); the one-workgroup walk below is its fallback
   // (a look at the chain is ~20 small launches and a synchronisation, ~0.4 ms before anything is decoded: below
@@ -1573,7 +1788,7 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
     const uint32_t oc = (uint32_t)(len - oo < kMaxBlockLen ? len - oo : kMaxBlockLen);
     if (stv[k] != kOk || olv[k] != oc) return -1;  // e.g. a copy that reaches into an earlier block
   }
-  if (!d_out_res) HIP_TRY(hipMemcpy(out, d_out, len, hipMemcpyDeviceToHost));
+  if (!d_out_res && (st = stage_download(c, out, d_out, (size_t)len, s, false))) return st;
   *written = (size_t)len;
   return SNAPPY_HIP_OK;
 }
@@ -1598,9 +1813,9 @@ extern "C" int snappy_hip_uncompress_d(snappy_hip_ctx* c, const uint8_t* d_in, u
   const int hdr = varint_decode(hb, hn, 32, &len);  // snappy.nim:92-94
   if (hdr <= 0) return SNAPPY_HIP_INVALID_INPUT;
   if (cap < len) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:96-97
-  if (len > kMaxBlockLen && s == c->stream) {
+  if (len > kMaxBlockLen) {
     size_t w = 0;
-    const int rs = uncompress_split_host(c, nullptr, (size_t)n, (uint32_t)hdr, len, nullptr, &w, d_in, d_out);
+    const int rs = uncompress_split_host(c, nullptr, (size_t)n, (uint32_t)hdr, len, nullptr, &w, d_in, d_out, s);
     if (rs >= 0) {
       *written = w;
       return rs;
@@ -1624,6 +1839,15 @@ extern "C" int snappy_hip_uncompress_d(snappy_hip_ctx* c, const uint8_t* d_in, u
   if (u.status != kOk) return (int)u.status;
   *written = u.out_len;
   return SNAPPY_HIP_OK;
+}
+
+extern "C" void snappy_hip_release_pool(void) {
+  std::vector<snappy_hip_ctx*> idle;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    idle.swap(g_pool);
+  }
+  for (snappy_hip_ctx* c : idle) snappy_hip_ctx_destroy(c);
 }
 
 extern "C" int snappy_hip_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap,

@@ -623,6 +623,9 @@ def test_shards_from_one_process_land_in_one_host_buffer(hip, orc, torch_mod):
         written, offs = hip.compress_shards(ctxs, d_ins, lens, out.data_ptr(), cap, framed=framed)
         assert out[:written].numpy().tobytes() == want
         assert offs[0] in (10, 4) and offs[-1] == written and offs[0] < offs[1] < offs[2]
+    # one context cannot serve two shards at once (it owns the scratch buffers its calls use)
+    with pytest.raises(ValueError):
+        hip.compress_shards([ctxs[0], ctxs[0]], d_ins, lens, out.data_ptr(), cap, framed=False)
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shards_one_process.py"), "--gpus", "2", "--same-gpu",
                          "--total-gib", "0.25", "--check", "--reps", "1"], capture_output=True, text=True, timeout=600)
     assert rc.returncode == 0, rc.stderr[-2000:]
@@ -742,3 +745,30 @@ def test_ring_window_decoder(hip, orc, torch_mod):
             crcs = d_crc.cpu().numpy().view(np.uint32)
             for j in range(0, nu, 97):
                 assert int(crcs[j]) == orc.masked_crc(units[j % n][1])
+
+
+def test_pool_release_and_caller_stream(hip, orc, torch_mod):
+    """snappy_hip_release_pool() frees the idle pooled contexts (calls after it make new ones); and
+    snappy_hip_uncompress_d on a CALLER's stream still splits a multi-block raw buffer on the device (the
+    result is the oracle's either way; the split is seen in the raw-split timer slot)"""
+    import corpus
+    torch = torch_mod
+    src = corpus.make_blocks(3, 40).tobytes()
+    enc = hip.encode(src)
+    assert enc == orc.encode(src)
+    hip.release_pool()
+    hip.release_pool()  # (nothing idle: a no-op)
+    assert hip.decode(enc) == src and hip.encode(src[:70000]) == orc.encode(src[:70000])
+    ctx = hip.Context(0)
+    d_raw = _dev(torch, np.frombuffer(enc, dtype=np.uint8))
+    d_out = torch.zeros(len(src), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ctx.timing(True)
+    assert ctx.uncompress(d_raw, len(enc), d_out, len(src), stream=st.cuda_stream) == (0, len(src))
+    st.synchronize()
+    ms, launches = ctx.kernel_ms(7)  # raw-buffer split rounds
+    ctx.timing(False)
+    assert launches > 0, "the caller's stream took the serial whole-stream kernel"
+    assert d_out.cpu().numpy().tobytes() == src
+    ctx.close()
