@@ -44,3 +44,22 @@ def test_model_equals_oracle_on_patterns_and_edges(orc):
         assert em.encode_block(b) == _oracle_block(orc, b)
     s = bytes(rnd.randrange(256) for _ in range(700))
     assert em.encode_block((s * 9)[:6000]) == _oracle_block(orc, (s * 9)[:6000])
+
+
+@pytest.mark.parametrize("R", [128, 256])
+def test_wide_round_model_equals_oracle(orc, R):
+    """tools/encode2_model.py: rounds of R = 128 / 256 consecutive positions (what several waves on one block
+    would work on) in front of the 64-lane rounds -- exact, and the statistics that decided against building it:
+    nearly every round of 256 is cut by a probe whose same-slot predecessor lies inside a copy."""
+    import encode2_model as e2
+    for name, off, n in (("alice29.txt", 0, 40000), ("html", 2000, 30000), ("geo.protodata", 0, 20000)):
+        blk = golden_file(name)[off:off + n]
+        st = {}
+        assert e2.encode_block(blk, R, st) == _oracle_block(orc, blk)
+        assert st.get("wide_rounds", 0) >= 1
+    txt = golden_file("alice29.txt")[:65536]
+    st = {}
+    assert e2.encode_block(txt, R, st) == _oracle_block(orc, txt)
+    # the measured reason: wide rounds advance far less than R positions each
+    assert st["wide_positions"] / st["wide_rounds"] < 0.9 * R
+    assert st["wide_cut"] > 0.3 * st["wide_rounds"]

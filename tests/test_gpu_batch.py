@@ -688,8 +688,9 @@ def _ring_stream(rng, target, style):
 
 def test_ring_window_decoder(hip, orc, torch_mod):
     """the indexed decoder's two instantiations (ring of the last 32 KiB first, whole block for the units it
-    passes on; whole block only when the CRC comes out of the decode kernel): foreign streams whose copies
-    reach behind the ring, wrap it, run across its end; outputs at unaligned addresses"""
+    passes on), without and with the CRC coming out of the decode kernels (the ring instantiation checksums
+    the rows its flush completes): foreign streams whose copies reach behind the ring, wrap it, run across
+    its end; outputs at unaligned addresses; output lengths of every residue mod 4 and mod 1024"""
     torch = torch_mod
     rng = random.Random(99)
     units = []
@@ -743,8 +744,9 @@ def test_ring_window_decoder(hip, orc, torch_mod):
         assert bad.size == 0, (with_crc, bad[:10], np.searchsorted(np.array(out_off), bad[:3], side="right") - 1)
         if with_crc:
             crcs = d_crc.cpu().numpy().view(np.uint32)
-            for j in range(0, nu, 97):
-                assert int(crcs[j]) == orc.masked_crc(units[j % n][1])
+            want_crc = [orc.masked_crc(p) for _, p in units]
+            bad_crc = [j for j in range(nu) if int(crcs[j]) != want_crc[j % n]]
+            assert not bad_crc, bad_crc[:10]
 
 
 def test_pool_release_and_caller_stream(hip, orc, torch_mod):

@@ -13,3 +13,6 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2>> $OUT/bench.err
 python3 $R/tools/profile_summary.py $OUT > $OUT/summary.md
 cat $OUT/summary.md
+# keep what is judged (summary, kernel stats, traffic.json, the bench lines); the raw traces stay on the box
+cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write

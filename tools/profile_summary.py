@@ -3,6 +3,8 @@ import collections, csv, glob, json, os, sys
 out = sys.argv[1]
 def short(k):
     # the indexed decoder's two instantiations: ring window first, whole-block window for what it passes on
+    if "decode_indexed_kernel<32768u, true" in k or "decode_indexed_kernelILj32768ELb1" in k:
+        return "decode_indexed_kernel<32768,crc>"  # (the ring instantiation that checksums the rows it flushes)
     for win in ("32768", "65536"):
         if "decode_indexed_kernel<%s" % win in k or "decode_indexed_kernelILj%s" % win in k:
             return "decode_indexed_kernel<%s>" % win
