@@ -57,21 +57,13 @@ __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
   return ((u * 0x1e35a7bdu) >> (32 - kMaxTableBits)) & mask;  // encoder.nim:36-37
 }
 
-#ifdef ENC_BLOCK_IN_LDS
-extern __shared__ __attribute__((aligned(16))) uint8_t s_enc_dyn[];
-#endif
 __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
   __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
-#ifdef ENC_BLOCK_IN_LDS
-  // EXPERIMENT (north_star's layout, profiles/README.md): the whole block staged in LDS -- the window
-  // is the block, candidates come from it; 105 KiB per block, so ONE block per CU instead of four
-  uint8_t* const s_win = s_enc_dyn;
-  constexpr uint32_t kWin = kMaxBlockLen + 32;
-#else
+  // (north_star's layout -- the whole block staged in LDS next to the table, one block per CU -- was built and
+  // measured in round 2: bit-exact, 3.8x slower; profiles/README.md)
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
   constexpr uint32_t kWin = kWinSize;
-#endif
   __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
   __shared__ uint16_t s_seq_step[kSeqLen];
 
@@ -404,22 +396,49 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     const uint32_t h = snappy_hash(d, mask);
     // (a lane without a position works on its private sink slot instead of being branched around)
     const uint32_t ti = valid ? h : tsink;
-    const uint32_t old = s_table[ti];
     uint4 cv;
-    uint4 cw = make_uint4(0, 0, 0, 0);  // for lanes whose candidate is another lane of the round
-    uint32_t cand = old;
     uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
-    bool any_conflict;
-    {
-      {
-        // The candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of
-        // encoder.nim:326 and, in fresh rounds, the first 16 bytes of findMatchLength.  This is the
-        // round's one trip to L2/HBM: it leaves as soon as the table has answered, and everything
-        // up to the comparison below (the table write, the lanes that share a slot, the previous
-        // round's output) happens while it is under way.
-#ifdef ENC_EARLY_FETCH
-        __builtin_memcpy(&cv, in + (valid ? old : 0), 16);
+    bool any_conflict = false;
+    uint32_t old = 0, cand = 0;
+    // ---- the table in ONE LDS trip (fresh rounds after a copy, away from ipLimit: every lane has a position) ----
+    // ds_mskor_rtn_b32 replaces my 16-bit slot inside its dword and returns the dword as it was.  Lanes on one
+    // address are served one after the other; served in ASCENDING lane order, a lane gets back the position of the
+    // nearest earlier lane of the round on its slot, else what the table held -- the candidate of the sequential
+    // loop with every earlier lane inserted, without the write / read back / write again of the plain form.  The
+    // order is not documented, so it is checked every time: a position of this round that a lane gets back must
+    // be an EARLIER lane's (any other order of service shows some lane a later one's); if not, the slots go back
+    // to what the first-served lanes saw and the plain form below does the round.
+#ifndef ENC_NO_ATOMIC_TABLE
+    bool atab = fresh && has0 && base + 96 <= ip_limit;
+#else
+    bool atab = false;
 #endif
+    const uint32_t sh16 = (h & 1) * 16;
+    const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_table[h & ~1u];
+    if (atab) {
+      uint32_t ret;
+      wave_fence();
+      asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(ret)
+                   : "v"(taddr), "v"(0xffffu << sh16), "v"((p & 0xffffu) << sh16)
+                   : "memory");
+      old = (ret >> sh16) & 0xffffu;
+      const bool inround = old >= base;  // (nothing at or behind base has been inserted before this round)
+      any_conflict = ballot(inround) != 0;
+      if (__builtin_expect(ballot(inround && old - base >= lane) != 0, 0)) {
+        wave_fence();
+        s_table[inround ? tsink : h] = (uint16_t)old;  // the first-served lane of every slot puts back what it saw
+        wave_fence();
+        atab = false;
+      } else {
+        cand = old;
+        dep = inround ? old - base : 64;
+      }
+    }
+    if (!atab) {
+      old = s_table[ti];
+      cand = old;
+      {
         wave_fence();
         s_table[ti] = (uint16_t)p;
         wave_fence();
@@ -466,51 +485,20 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           }
           losers &= ~g;
         }
-#if defined(ENC_BLOCK_IN_LDS)
-        cv = make_uint4(0, 0, 0, 0);
-        {
-          const uint32_t qa = valid ? (cand + shift - wq) : 0;
-          const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
-          const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
-          const uint32_t sh8 = (qa & 3) * 8;
-          cv.x = __funnelshift_r(r0, r1, sh8);
-          cv.y = __funnelshift_r(r1, r2, sh8);
-          cv.z = __funnelshift_r(r2, r3, sh8);
-          cv.w = __funnelshift_r(r3, r4, sh8);
-        }
-        if (0) {
-#elif !defined(ENC_EARLY_FETCH)
-        __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
-        if (0) {
-#else
-        if (any_conflict) {  // lanes whose candidate is another lane of the round: its bytes instead
-#endif
-          if (fresh) {       // ... which lie in the window (a continuing round stops in front of such a lane)
-            const uint32_t qa = dep < 64 ? (cand + shift - wq) : 0;
-            const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
-            const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
-            const uint32_t sh8 = (qa & 3) * 8;
-            cw.x = __funnelshift_r(r0, r1, sh8);
-            cw.y = __funnelshift_r(r1, r2, sh8);
-            cw.z = __funnelshift_r(r2, r3, sh8);
-            cw.w = __funnelshift_r(r3, r4, sh8);
-          }
-        }
-        tick(1);  // table read / write / read back, conflicts
       }
     }
+    // The candidate's 16 bytes (cand < p, so cand + 16 <= n): the 4-byte check of encoder.nim:326 and, in fresh
+    // rounds, the first 16 bytes of findMatchLength.  This is the round's one trip to L2/HBM: it leaves as soon as
+    // the table has answered, and the previous round's output is written while it is under way.
+    __builtin_memcpy(&cv, in + (valid ? cand : 0), 16);
+    tick(1);  // table, conflicts
     drain();  // the previous round's elements, while the candidates are in flight
     tick(2);  // drain
 
-#ifndef ENC_EARLY_FETCH
-    const bool inr = false;
-#else
-    const bool inr = dep < 64;
-#endif
-    const uint64_t m4 = ballot(valid && (inr ? cw.x : cv.x) == d);
+    const uint64_t m4 = ballot(valid && cv.x == d);
     uint32_t eq;  // equal leading bytes, 4..16 (meaningful where the 4-byte check passed)
     {
-      const uint32_t x1 = pd1 ^ (inr ? cw.y : cv.y), x2 = pd2 ^ (inr ? cw.z : cv.z), x3 = pd3 ^ (inr ? cw.w : cv.w);
+      const uint32_t x1 = pd1 ^ cv.y, x2 = pd2 ^ cv.z, x3 = pd3 ^ cv.w;
       const uint32_t e3 = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : 16;
       const uint32_t e2 = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : e3;
       eq = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : e2;
@@ -721,7 +709,15 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       tick(6);  // chain: what was inserted, what is covered (and the general chain)
       // ---- leave the table as the lanes the sequential loop touched would have left it ---------
       wave_fence();
-      if (!any_conflict) {  // every lane has a slot of its own: the others take their writes back
+      if (atab) {
+        // (the same service in ascending lane order, checked above for these very lanes and addresses: the
+        // first-served lane of a slot -- it saw what the table held -- restores that unless it stays inserted,
+        // every later lane that stays inserted overwrites: the last inserted lane of a slot writes last)
+        const bool firstm = old < base;
+        const uint32_t mk = (firstm || in_s) ? 0xffffu : 0u;
+        const uint32_t dv = in_s ? (p & 0xffffu) : (firstm ? old : 0u);  // (nothing is OR-ed in where nothing is masked out)
+        asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"(mk << sh16), "v"(dv << sh16) : "memory");
+      } else if (!any_conflict) {  // every lane has a slot of its own: the others take their writes back
         s_table[(valid && !in_s) ? h : tsink] = (uint16_t)old;
       } else {              // of the lanes on one slot the last one that was touched wrote last
         const uint64_t gs = grp & ballot(in_s);

@@ -447,14 +447,8 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   }
   {
     LaunchTimer lt(c, s, 1);
-#ifdef ENC_BLOCK_IN_LDS
-    HIP_TRY(hipFuncSetAttribute((const void*)encode_blocks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kMaxBlockLen + 64));
-    LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64), kMaxBlockLen + 64, s, p);
-#else
     LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
            dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
-#endif
   }
   if (d_estats) {
     unsigned long long h[16];
@@ -1587,7 +1581,8 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // -1: not applicable (the chain is not complete within the looks, an invalid or foreign element lies on it, a
 // candidate list overflowed, an element straddles a block boundary).
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
-                      uint32_t* d_blk, hipStream_t s) {
+                      uint32_t* d_blk, hipStream_t s, uint32_t* d_ol, uint32_t* d_bad, const uint64_t** d_total,
+                      const uint32_t** d_flags) {
   // rounds before the first look at the chain (text-like data is complete by then), between later looks
   // (a handful of late candidates), looks before the serial walk takes over
   constexpr int kRoundsFirst = 4, kRoundsLater = 4, kMaxLooks = 6;
@@ -1618,8 +1613,11 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   uint32_t* flags = (uint32_t*)q;
   q += 32;
   uint8_t* reach = q;
-  HIP_TRY(hipMemsetAsync(ent, 0xff, nodes * 8, s));  // ent and ext: no candidates, nothing walked
-  HIP_TRY(hipMemsetAsync(counters, 0, 64, s));       // and the flags
+  {  // ent and ext: no candidates but the root, nothing walked; counters and flags; block starts, lengths, verdict
+    const uint32_t ig = (uint32_t)((nodes * 2 + 255) / 256 < 1024 ? (nodes * 2 + 255) / 256 : 1024);
+    LAUNCH(split_init_kernel, dim3(ig), dim3(256), 0, s, ent, (uint64_t)nodes * 2, counters, d_blk, (uint32_t)(nblk + 1), d_ol,
+           (uint32_t)nblk, d_bad);
+  }
   SplitParams sp{};
   sp.in = d_tags;
   sp.n = n_tags;
@@ -1633,13 +1631,12 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;
+  sp.nblk = (uint32_t)nblk;
   const uint32_t grid = (nseg + 255) / 256;
   const uint32_t ngrid = (uint32_t)((nodes + 255) / 256);
   const uint32_t wgrid = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 16 KiB of staged stream each)
   HIP_TRY(hipFuncSetAttribute((const void*)split_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   HIP_TRY(hipFuncSetAttribute((const void*)split_locate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
-  const uint32_t root = kSplitTrusted;  // (node 0: position 0, no guess)
-  HIP_TRY(hipMemcpyAsync(ent, &root, 4, hipMemcpyHostToDevice, s));
   int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
   while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
   bool done = false;
@@ -1677,18 +1674,13 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, (const uint32_t*)tile_sum, (uint64_t)tiles, (uint64_t)0, tile_base);
     LAUNCH(split_tile_scan_kernel, dim3(tiles), dim3(256), 0, s, (const uint32_t*)outb, nseg, (const uint64_t*)tile_base, out_at);
   }
-  uint64_t total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, out_at + nseg, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (total != len) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:107-108
-  (void)nblk;
+  // (the total -- snappy.nim:107-108 -- and the last walk's flags are judged on the device, by split_table_kernel: the
+  // host looks once, behind the decode; a total that is not the declared length writes no block start beyond the table)
+  (void)len;
   LAUNCH(split_locate_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
   HIP_TRY(hipGetLastError());
-  uint32_t h_flags[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (h_flags[1]) return SNAPPY_HIP_INVALID_INPUT;
-  if (h_flags[2]) return -1;
+  *d_total = out_at + nseg;
+  *d_flags = flags;
   return SNAPPY_HIP_OK;
 }
 
@@ -1718,16 +1710,25 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   if ((st = ws_get(c, 10, 64, &d_one))) return st;
   hipStream_t s = on ? on : c->stream;  // (the device-resident entry point passes the caller's stream on)
   if (!d_in_res && (st = stage_upload(c, d_in, in, n, s, true))) return st;
-  HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+  uint32_t* d_bad = (uint32_t*)d_one + 6;  // d_one[6]: the split's verdict (split_table_kernel)
+  const uint64_t* d_total = nullptr;
+  const uint32_t* d_flags = nullptr;
   // first the speculative parallel walk (split_kernels.h); the one-workgroup walk below is its fallback
   // (a look at the chain is ~20 small launches and a synchronisation, ~0.4 ms before anything is decoded: below
   // ~200 KiB of stream the one-workgroup walk, 1 GB/s, is there first)
   constexpr size_t kSpecMinStream = 192 << 10;
   const int spec = (dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT") || n - hdr < kSpecMinStream)
                        ? -1
-                       : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk, s);
+                       : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk, s,
+                                           (uint32_t*)d_ol, d_bad, &d_total, &d_flags);
   if (spec > 0) return spec;
-  if (spec < 0) HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+  if (spec < 0) {  // (not tried, or given up: the one-workgroup walk starts from a clean table)
+    d_total = nullptr;
+    d_flags = nullptr;
+    HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
+  }
   // the splitter's one unit: [in_off u64 | in_len u32 | out_cap u32 | out_len u32 | status u32]
   struct {
     uint64_t in_off;
@@ -1767,11 +1768,9 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
     if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
   }
   // the blocks as units, on the device (no trip to the host in between); d_one[6]: a block without a start
-  uint32_t* d_bad = (uint32_t*)d_one + 6;
-  HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
   LAUNCH(split_table_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_blk, (uint32_t)nblk,
-         (uint32_t)(n - hdr), hdr, len, (uint64_t*)d_io, (uint32_t*)d_il, (uint64_t*)d_oo, (uint32_t*)d_oc, d_bad);
-  HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
+         (uint32_t)(n - hdr), hdr, len, (uint64_t*)d_io, (uint32_t*)d_il, (uint64_t*)d_oo, (uint32_t*)d_oc, d_bad, d_total,
+         d_flags);
   if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nblk,
                      (int)kUnitBody, nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
                      (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
@@ -1782,6 +1781,7 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   HIP_TRY(hipMemcpyAsync(olv.data(), d_ol, nblk * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (h_bad & 2) return SNAPPY_HIP_INVALID_INPUT;  // (the speculative walk saw the whole stream: its verdict stands)
   if (h_bad) return -1;
   for (size_t k = 0; k < nblk; k++) {
     const uint64_t oo = (uint64_t)k * kMaxBlockLen;

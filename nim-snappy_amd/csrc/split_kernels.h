@@ -59,7 +59,22 @@ struct SplitParams {
   uint32_t* flags;        // [1] invalid element met, [2] an element straddles a 64 KiB boundary of the output
   const uint64_t* out_at; // [nseg + 1] exclusive prefix sum of outb
   uint32_t* blk_in;       // [nblk] stream position where output block k starts
+  uint32_t nblk;          // (blk_in's length: a total that is not the declared length must not write beyond it)
 };
+
+// Everything the split starts from, in one launch (eight fills and copies of a few bytes each cost 0.2 ms of
+// launch gaps in front of the first walk): candidate lists empty but for the root, nothing walked, counters and
+// flags zero, no block start known, no unit length, no verdict.
+__global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint64_t n_ent_ext, uint32_t* counters16,
+                                                         uint32_t* blk, uint32_t n_blk, uint32_t* out_len, uint32_t n_len,
+                                                         uint32_t* bad) {
+  const uint64_t t = blockIdx.x * 256ull + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = t; i < n_ent_ext; i += stride) ent_ext[i] = i == 0 ? kSplitTrusted : 0xffffffffu;  // (node 0: position 0)
+  for (uint64_t i = t; i < n_blk; i += stride) blk[i] = 0xffffffffu;
+  for (uint64_t i = t; i < n_len; i += stride) out_len[i] = 0;
+  if (t < 16) counters16[t] = 0;
+  if (t == 0) *bad = 0;
+}
 
 // One wave per workgroup: its 64 segments are 16 KiB of stream, staged in LDS with coalesced loads
 // before the lanes walk them (64 lanes reading their own segment byte by byte straight from memory move
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
       p.flags[1] = 1;
       return;
     }
-    if ((op & 0xffffu) == 0) p.blk_in[op >> 16] = pos;
+    if ((op & 0xffffu) == 0 && (op >> 16) < p.nblk) p.blk_in[op >> 16] = pos;
     else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
     op += L;
     pos += size;
@@ -302,14 +317,25 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
 }
 
 // the blocks as units of the block decoder, from where they start in the stream (blk_in[k], k >= 1; block 0 at 0)
+// *bad: 1 = a block without a start (the caller falls back to the serial walk), 2 = the stream is invalid (its
+// elements do not produce the declared length, snappy.nim:107-108, or the last walk met an invalid one), 4 = an
+// element straddles a 64 KiB boundary (a foreign encoder: fall back) -- the speculative split's verdicts, looked
+// at by the host once, behind the decode
 __global__ __launch_bounds__(256) void split_table_kernel(const uint32_t* blk_in, uint32_t nblk, uint32_t n_tags,
                                                           uint32_t hdr, uint64_t len, uint64_t* in_off, uint32_t* in_len,
-                                                          uint64_t* out_off, uint32_t* out_cap, uint32_t* bad) {
+                                                          uint64_t* out_off, uint32_t* out_cap, uint32_t* bad,
+                                                          const uint64_t* total, const uint32_t* flags) {
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k == 0 && total) {
+    uint32_t v = 0;
+    if (*total != len || flags[1]) v |= 2;
+    if (flags[2]) v |= 4;
+    if (v) atomicOr(bad, v);
+  }
   if (k >= nblk) return;
   const uint32_t b0 = k == 0 ? 0 : blk_in[k], b1 = k + 1 == nblk ? n_tags : blk_in[k + 1];
   const bool ok = b0 != 0xffffffffu && b1 != 0xffffffffu && b1 >= b0 && b1 <= n_tags;
-  if (!ok) *bad = 1;  // (a block nobody recorded the start of: the caller falls back; the unit is made empty)
+  if (!ok) atomicOr(bad, 1u);  // (a block nobody recorded the start of: the caller falls back; the unit is made empty)
   const uint64_t oo = (uint64_t)k * kMaxBlockLen;
   in_off[k] = (uint64_t)hdr + (ok ? b0 : 0);
   in_len[k] = ok ? b1 - b0 : 0;
