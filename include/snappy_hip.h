@@ -176,6 +176,10 @@ int snappy_hip_uncompress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uin
 int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
                                const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
                                uint64_t* written, uint64_t* shard_off);
+/* Batches of 512 units or more are launched in a sorted order (decode: by compressed length, longest first; encode:
+ * by a sketch of the block), which costs three small launches and is worth ~10 % on mixed batches; results never
+ * depend on it.  enable = 0 launches in the caller's order (default 1). */
+int snappy_hip_ctx_launch_order(snappy_hip_ctx* ctx, int enable);
 /* Average duration in milliseconds of the last timed kernel launches, measured with HIP
  * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
  * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
     "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d", "snappy_hip_uncompress_d",
-    "snappy_hip_compress_shards", "snappy_hip_release_pool",
+    "snappy_hip_compress_shards", "snappy_hip_release_pool", "snappy_hip_ctx_launch_order",
 ]
 
 
@@ -104,6 +104,7 @@ lib.snappy_hip_uncompress_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c
 lib.snappy_hip_release_pool.restype = None
 lib.snappy_hip_release_pool.argtypes = []
 lib.snappy_hip_ctx_timing.argtypes = [_vp, ctypes.c_int]
+lib.snappy_hip_ctx_launch_order.argtypes = [_vp, ctypes.c_int]
 lib.snappy_hip_ctx_kernel_ms.restype = ctypes.c_double
 lib.snappy_hip_ctx_kernel_ms.argtypes = [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
 
@@ -378,6 +379,10 @@ class Context:
         st = _check_device(lib.snappy_hip_uncompress_d(self._h, _ptr(d_in), n, _ptr(d_out), cap,
                                                        ctypes.byref(w), stream))
         return st, w.value
+
+    def launch_order(self, enable):
+        """large batches in sorted launch order (default) or in the caller's order"""
+        lib.snappy_hip_ctx_launch_order(self._h, int(enable))
 
     def timing(self, enable):
         lib.snappy_hip_ctx_timing(self._h, int(enable))

@@ -43,8 +43,9 @@ thread_local std::string g_last_error;
     }                                                                                        \
   } while (0)
 
-// Debug knobs (profiles/README.md) are read only by builds with -DSNAPPY_HIP_DEBUG; the shipped
-// library ignores the environment (SNAPPY_HIP_DEVICE, the default context's device, excepted).
+// Debug knobs (profiles/README.md) are read only by builds with -DSNAPPY_HIP_DEBUG.  The shipped library reads
+// four tuning knobs of the host-buffer calls, once (include/snappy_hip.h documents them): SNAPPY_HIP_DEVICE,
+// SNAPPY_HIP_HOST_BATCH, SNAPPY_HIP_PIN_HOST, SNAPPY_HIP_COPY_THREADS; the device-resident API reads none.
 #ifdef SNAPPY_HIP_DEBUG
 inline const char* dbg_env(const char* name) { return getenv(name); }
 #else
@@ -126,6 +127,7 @@ struct snappy_hip_ctx {
   hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_busy[4] = {false, false, false, false};
   bool stage_failed = false;       // the ring could not be allocated: copies go the runtime's pageable way
+  bool launch_order = true;        // batches of >= 512 units are launched in sorted order (snappy_hip_ctx_launch_order)
   bool timing = false;
   struct Timed {
     hipEvent_t a, b;
@@ -310,6 +312,11 @@ extern "C" int snappy_hip_ctx_sync(snappy_hip_ctx* c, void* stream) {
   return SNAPPY_HIP_OK;
 }
 
+extern "C" int snappy_hip_ctx_launch_order(snappy_hip_ctx* c, int enable) {
+  c->launch_order = enable != 0;
+  return SNAPPY_HIP_OK;
+}
+
 extern "C" int snappy_hip_ctx_timing(snappy_hip_ctx* c, int enable) {
   c->timing = enable != 0;
   if (enable) {
@@ -430,7 +437,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   p.crc = d_crc;
   p.seq_off = c->d_seq_off;
   p.seq_step = c->d_seq_step;
-  if (nb >= 512 && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: blocks that look alike together
+  if (nb >= 512 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: blocks that look alike together
     void *d_sk, *d_perm;
     int st = ws_get(c, 16, nb * 8 + kOrderBuckets * 4, &d_sk);
     if (st) return st;
@@ -552,7 +559,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.n_units = n_units;
     dp.unit = unit;
     if (const char* e = dbg_env("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
-    if (n_units >= 512 && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
+    if (n_units >= 512 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
       void* d_perm;
       if ((st = launch_order(c, d_in_len, n_units, kOrderByLength, 15, 0, s, &d_perm))) return st;
       ip.order = (const uint32_t*)d_perm;

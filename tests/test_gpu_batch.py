@@ -497,8 +497,7 @@ def test_launch_order_large_batch(hip, orc, torch_mod):
     d_stream = _dev(torch, np.frombuffer(bytes(stream) + b"\0" * 64, dtype=np.uint8))
     results = []
     for no_order in (False, True):
-        if no_order:
-            os.environ["SNAPPY_HIP_NO_ORDER"] = "1"
+        ctx.launch_order(not no_order)  # (snappy_hip_ctx_launch_order: sorted launch order / the caller's order)
         try:
             d_out = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
             d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
@@ -508,7 +507,7 @@ def test_launch_order_large_batch(hip, orc, torch_mod):
                               _dev(torch, cap), d_out_len, d_status, unit=hip.UNIT_RAW, d_crc=d_crc)
             ctx.sync()
         finally:
-            os.environ.pop("SNAPPY_HIP_NO_ORDER", None)
+            ctx.launch_order(True)
         assert (d_status.cpu().numpy() == 0).all()
         ol = d_out_len.cpu().numpy()
         out = d_out.cpu().numpy()
