@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   // measured in round 2: bit-exact, 3.8x slower; profiles/README.md)
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
   constexpr uint32_t kWin = kWinSize;
+  __shared__ uint32_t s_cold[8];             // the rarely pending output items (see below)
   __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
   __shared__ uint16_t s_seq_step[kSeqLen];
 
@@ -126,9 +127,24 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   uint64_t dp_ms = 0;                   //     lanes where a copy starts
   bool dp_lit = false;                  //     per lane: its byte is a literal byte
   uint32_t dp_len = 0, dp_off = 0, dp_byte = 0;  // per lane: copy length, copy offset, the byte at the lane's position
-  uint32_t lit_from = 0, lit_len = 0;   // (2) one literal ...
-  uint32_t cp_off = 0, cp_len = 0;      // (3) ... one copy ...
-  uint32_t lit2_from = 0, lit2_len = 0; // (4) ... and the block's final literal (encoder.nim:249-253)
+  // (2)-(4) are set on the rare paths only (a long scan, a copy of more than 64 bytes, the block's end): they live in
+  // LDS, behind one flag in a register -- the parse loop is short of scalar registers (every spilled one is a
+  // v_readlane / v_writelane on the round's chain of instructions)
+  struct ColdU32 {
+    volatile uint32_t* p;
+    __device__ __forceinline__ operator uint32_t() const { return readfirst(*p); }
+    __device__ __forceinline__ ColdU32& operator=(uint32_t v) {
+      if (lane_id() == 0) *p = v;
+      return *this;
+    }
+    __device__ __forceinline__ ColdU32& operator=(const ColdU32& o) { return *this = (uint32_t)o; }  // (the value, not the slot)
+  };
+  if (lane < 8) s_cold[lane] = 0;
+  wave_fence();
+  bool cold_any = false;                // one of (2)-(4) is set
+  ColdU32 lit_from{&s_cold[0]}, lit_len{&s_cold[1]};    // (2) one literal ...
+  ColdU32 cp_off{&s_cold[2]}, cp_len{&s_cold[3]};       // (3) ... one copy ...
+  ColdU32 lit2_from{&s_cold[4]}, lit2_len{&s_cold[5]};  // (4) ... and the block's final literal (encoder.nim:249-253)
   // The elements of a fresh round.  One prefix sum places them all: a lane holding a literal byte
   // writes it (the first lane of a run also the tag, emitLiteral encoder.nim:44-73: runs are <= 63
   // bytes), a lane where a copy starts writes the copy (emitCopy :81-125; lengths <= 64 only, so
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     ofill += total;
   };
   auto drain = [&]() {
-    if (dpend && ofill <= kObFlushAt && (lit_len | cp_len | lit2_len) == 0 && !finished) {  // the usual case
+    if (dpend && ofill <= kObFlushAt && !cold_any && !finished) {  // the usual case
       emit_round();
       return;
     }
@@ -265,6 +281,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
       break;
     }
+    cold_any = false;
   };
 
   // per-block setup (encoder.nim:227-245)
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     finished = true;
     lit2_from = 0;
     lit2_len = n;
+    cold_any = true;
   } else {
     uint32_t table_size = 1u << 8;
     while (table_size < kMaxTableSize && table_size < n) table_size <<= 1;
@@ -391,6 +409,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       finished = true;
       lit2_from = next_emit;
       lit2_len = n - next_emit;
+      cold_any = true;
       break;
     }
     const uint32_t h = snappy_hash(d, mask);
@@ -738,6 +757,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           dp_ms &= ~(1ull << mlast);
           cp_off = base + mlast - readlane(cand, mlast);
           cp_len = llast;
+          cold_any = true;
         }
         dp_lit = !covered && lane >= (has0 ? 1u : 0u) && lane < e;
         dp_len = lens;
@@ -749,6 +769,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         finished = true;
         lit2_from = tail_from;
         lit2_len = n - tail_from;  // (may be 0)
+        cold_any = true;
         break;
       }
       has0 = n_has0;
@@ -790,6 +811,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       finished = true;  // encoder.nim:319-321
       lit2_from = next_emit;
       lit2_len = n - next_emit;
+      cold_any = true;
       break;
     }
     const uint32_t pm = readlane(p, m_eff);
@@ -799,11 +821,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     lit_len = pm - next_emit;
     cp_off = pm - c;
     cp_len = matched;
+    cold_any = true;
     const uint32_t ip = pm + matched;
     if (ip > ip_limit) {  // encoder.nim:362 -- strictly greater
       finished = true;
       lit2_from = ip;
       lit2_len = n - ip;
+      cold_any = true;
       break;
     }
     // next round: insert of ip - 1 (:371), probe at ip (:373-380), scan from ip + 1
