@@ -370,6 +370,198 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   // the lanes a copy that ends at THIS lane looks at next: its copy-loop probe, then the scan's probes
   const uint64_t mine = ((kScanPat << 1) | 1ull) << lane;
   while (!finished) {
+#ifndef ENC_NO_FAST_LOOP
+    // ==== the common round in a loop of its own =====================================================================
+    // A fresh round right after a copy, away from ipLimit (every lane has a position, every probe of the pattern
+    // runs), whose chain finds a match from its first copy end: nine rounds in ten of text.  Same steps as the
+    // general round below -- which takes over, from the same state, whenever this one declines (nothing found from the
+    // first end, a wrong candidate in the first segment, the table's order of service not ascending) -- but with
+    // nothing of the general round's state alive in it.
+    while (has0 && idx0 == 0 && s0 - 2 + 96 <= ip_limit) {
+      const uint32_t base = s0 - 2;
+      if (!in_window(base, 96)) fill_window(base);
+      rounds++;
+      const uint32_t p = base + lane;
+      uint32_t d, pd1, pd2, pd3;
+      {
+        const uint32_t qa = p + shift - wq;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+        const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
+        const uint32_t sh8 = (qa & 3) * 8;
+        d = __funnelshift_r(r0, r1, sh8);
+        pd1 = __funnelshift_r(r1, r2, sh8);
+        pd2 = __funnelshift_r(r2, r3, sh8);
+        pd3 = __funnelshift_r(r3, r4, sh8);
+      }
+      tick(0);
+      const uint32_t h = snappy_hash(d, mask);
+      const uint32_t sh16 = (h & 1) * 16;
+      const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_table[h & ~1u];
+      uint32_t old;
+      {  // the table in one trip (see the general round)
+        uint32_t ret;
+        wave_fence();
+        asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ret)
+                     : "v"(taddr), "v"(0xffffu << sh16), "v"((p & 0xffffu) << sh16)
+                     : "memory");
+        old = (ret >> sh16) & 0xffffu;
+      }
+      const bool inround = old >= base;
+      const uint64_t conf = ballot(inround);  // lanes whose candidate is another lane of the round
+      // puts the slots back to what the first-served lanes saw (the round is then done by the general form)
+      auto undo_table = [&]() {
+        wave_fence();
+        asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"((inround ? 0u : 0xffffu) << sh16), "v"((inround ? 0u : old) << sh16)
+                     : "memory");
+        wave_fence();
+      };
+      if (__builtin_expect(ballot(inround && old - base >= lane) != 0, 0)) {  // not served in ascending order
+        undo_table();
+        break;
+      }
+      const uint32_t cand = old;
+      const uint32_t dep = inround ? old - base : 64;
+      uint4 cv;
+      __builtin_memcpy(&cv, in + cand, 16);
+      tick(1);
+      drain();  // the previous round's elements, while the candidates are in flight
+      tick(2);
+      const uint64_t m4 = ballot(cv.x == d);
+      uint32_t eq;
+      {
+        const uint32_t x1 = pd1 ^ cv.y, x2 = pd2 ^ cv.z, x3 = pd3 ^ cv.w;
+        const uint32_t e3 = x3 ? 12 + ((uint32_t)__builtin_ctz(x3) >> 3) : 16;
+        const uint32_t e2 = x2 ? 8 + ((uint32_t)__builtin_ctz(x2) >> 3) : e3;
+        eq = x1 ? 4 + ((uint32_t)__builtin_ctz(x1) >> 3) : e2;
+      }
+      tick(3);
+      // ---- the chain (see the general round) ----
+      uint64_t MS = 0, E = 0;
+      uint32_t lens = eq, e = 1;
+      {
+        const uint64_t cnd = mine & m4;
+        const uint32_t mv = cnd ? ctz64(cnd) : 64;
+        const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)(eq | (eq == 16 ? 0x100u : 0u)));
+        const uint32_t nxt = mv == 64 ? 255u : ((lm & 0x100u) ? 254u : mv + lm);
+        const uint32_t pk = nxt | (mv << 8);
+        const uint32_t pk2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nxt & 63) << 2), (int)pk);
+        const uint32_t P = pk | (pk2 << 16);
+        tick(4);
+        uint32_t x = readlane(P, e);
+        uint32_t t, m;
+        for (;;) {
+          {
+            uint64_t tmp;
+            asm volatile(
+                "1:\n"
+                "s_and_b32 %[t], %[x], 0xff\n"
+                "s_bfe_u32 %[m], %[x], 0x80008\n"
+                "s_cmp_lt_u32 %[t], 63\n"
+                "s_cbranch_scc0 2f\n"
+                "s_lshl_b64 %[tmp], 1, %[e]\n"
+                "s_or_b64 %[E], %[E], %[tmp]\n"
+                "s_lshl_b64 %[tmp], 1, %[m]\n"
+                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_mov_b32 %[e], %[t]\n"
+                "s_bfe_u32 %[t], %[x], 0x80010\n"
+                "s_lshr_b32 %[m], %[x], 24\n"
+                "s_cmp_lt_u32 %[t], 63\n"
+                "s_cbranch_scc0 2f\n"
+                "s_lshl_b64 %[tmp], 1, %[e]\n"
+                "s_or_b64 %[E], %[E], %[tmp]\n"
+                "s_lshl_b64 %[tmp], 1, %[m]\n"
+                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_mov_b32 %[e], %[t]\n"
+                "v_readlane_b32 %[x], %[P], %[e]\n"
+                "s_branch 1b\n"
+                "2:\n"
+                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x), [tmp] "=&s"(tmp)
+                : [P] "v"(P)
+                : "scc");
+          }
+          if (t == 255) break;
+          E |= 1ull << e;
+          MS |= 1ull << m;
+          if (t == 254) {
+            const uint32_t matched = 16 + extend_match(readlane(cand, m) + 16, base + m + 16);
+            lens = lane == m ? matched : lens;
+            e = m + matched;
+          } else {
+            e = t;
+          }
+          if (e > 62) break;
+          x = readlane(P, e);
+        }
+        tick(5);
+      }
+      bool covered = false, in_s = false;
+      if (MS) {
+        const uint32_t endv = ((MS >> lane) & 1) ? lane + lens : 0;
+        uint32_t unused;
+        uint32_t ce = wave_excl_scan_max(endv, lane, &unused);
+        ce = ce > 1 ? ce : 1;
+        covered = lane < (ce > endv ? ce : endv);
+        const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
+        const uint32_t o = lane - ce - 1;
+        const bool on_pat = (lane == ce) | (o < 32) | ((o & 1) == 0);
+        const bool last_byte = lane + 1 == ce;
+        in_s = (lane <= mlast) & ((lane >= ce) ? on_pat : last_byte);
+        if (conf) {
+          const uint64_t S = ballot(in_s);
+          const uint64_t bad = ballot(dep < 64 && !((S >> (dep & 63)) & 1)) & S & ~(E >> 1);
+          if (bad) {
+            const uint32_t fb = ctz64(bad);
+            const uint64_t eb = E & ((2ull << fb) - 1);
+            e = 63 - (uint32_t)__builtin_clzll(eb);
+            MS &= (1ull << e) - 1;
+            covered = covered && lane < e;
+            in_s = in_s && lane + 1 < e;
+          }
+        }
+      }
+      tick(6);
+      if (MS == 0) {  // nothing to keep of this round: the general round does it from the same state
+        undo_table();
+        break;
+      }
+      {  // the table as the inserted lanes leave it (see the general round)
+        const bool firstm = old < base;
+        const uint32_t mk = (firstm || in_s) ? 0xffffu : 0u;
+        const uint32_t dv = in_s ? (p & 0xffffu) : (firstm ? old : 0u);
+        wave_fence();
+        asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"(mk << sh16), "v"(dv << sh16) : "memory");
+        wave_fence();
+      }
+      {  // hand the elements over
+        const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
+        const uint32_t llast = readlane(lens, mlast);
+        dpend = true;
+        dp_ms = MS;
+        if (llast > 64) {  // a long last copy goes the general way
+          dp_ms &= ~(1ull << mlast);
+          cp_off = base + mlast - readlane(cand, mlast);
+          cp_len = llast;
+          cold_any = true;
+        }
+        dp_lit = !covered && lane >= 1u && lane < e;
+        dp_len = lens;
+        dp_off = p - cand;
+        dp_byte = d & 0xff;
+      }
+      tick(7);
+      next_emit = base + e;
+      s0 = base + e + 1;
+      if (base + e > ip_limit) {  // encoder.nim:362 -- strictly greater (only after a long copy)
+        finished = true;
+        lit2_from = base + e;
+        lit2_len = n - (base + e);
+        cold_any = true;
+        break;
+      }
+    }
+    if (finished) break;
+#endif
     // ---- this round's position per lane, and 16 bytes of input there ---------------------------
     const bool fresh = idx0 == 0;
     uint32_t p = 0, d = 0, dep = 64, base = 0;
