@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   uint32_t idx0 = 0;        // index into the probe sequence of a continuing round's first lane
 
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // DEBUG section timers
-  uint32_t rounds = 0;
+  uint32_t rounds = 0, c_fast = 0, c_bail_ms = 0, c_bail_order = 0, c_cont = 0, c_fresh_nohas = 0;  // DEBUG
   auto tick = [&](int k) {
     if (SNAPPY_STATS(prm)) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 #ifndef ENC_NO_FAST_LOOP
     // ==== the common round in a loop of its own =====================================================================
     // A fresh round right after a copy, away from ipLimit (every lane has a position, every probe of the pattern
-    // runs), whose chain finds a match from its first copy end: nine rounds in ten of text.  Same steps as the
+    // runs), whose chain finds a match from its first copy end: 1 057 of a text block's 1 062 rounds.  Same steps as the
     // general round below -- which takes over, from the same state, whenever this one declines (nothing found from the
     // first end, a wrong candidate in the first segment, the table's order of service not ascending) -- but with
     // nothing of the general round's state alive in it.
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       };
       if (__builtin_expect(ballot(inround && old - base >= lane) != 0, 0)) {  // not served in ascending order
         undo_table();
+        c_bail_order++;
         break;
       }
       const uint32_t cand = old;
@@ -523,8 +524,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       tick(6);
       if (MS == 0) {  // nothing to keep of this round: the general round does it from the same state
         undo_table();
+        c_bail_ms++;
         break;
       }
+      c_fast++;
       {  // the table as the inserted lanes leave it (see the general round)
         const bool firstm = old < base;
         const uint32_t mk = (firstm || in_s) ? 0xffffu : 0u;
@@ -564,6 +567,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 #endif
     // ---- this round's position per lane, and 16 bytes of input there ---------------------------
     const bool fresh = idx0 == 0;
+    if (!fresh) c_cont++;
+    if (fresh && !has0) c_fresh_nohas++;
     uint32_t p = 0, d = 0, dep = 64, base = 0;
     uint32_t pd1 = 0, pd2 = 0, pd3 = 0;
     bool valid = false;
@@ -1032,6 +1037,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   if (SNAPPY_STATS(prm) && lane == 0) {
     for (int k = 0; k < 8; k++) atomicAdd(&prm.stats[k], tacc[k]);
     atomicAdd(&prm.stats[8], (unsigned long long)rounds);
+    atomicAdd(&prm.stats[9], (unsigned long long)c_fast);
+    atomicAdd(&prm.stats[10], (unsigned long long)c_bail_ms);
+    atomicAdd(&prm.stats[11], (unsigned long long)c_bail_order);
+    atomicAdd(&prm.stats[12], (unsigned long long)c_cont);
+    atomicAdd(&prm.stats[13], (unsigned long long)c_fresh_nohas);
   }
   uint32_t body_len = gpos;
 

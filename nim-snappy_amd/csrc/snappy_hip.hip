@@ -462,6 +462,8 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
     HIP_TRY(hipMemcpyAsync(h, d_estats, 128, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double r = h[8] ? (double)h[8] : 1.0;
+    fprintf(stderr, "ENC STATS per block: fast rounds %.1f, left the fast loop: nothing from the first end %.1f, order %.2f; continuing rounds %.1f, fresh without a copy before %.1f\n",
+            h[9] / (double)nb, h[10] / (double)nb, h[11] / (double)nb, h[12] / (double)nb, h[13] / (double)nb);
     fprintf(stderr, "ENC STATS rounds/block %.0f; ticks per round: probe %.0f table+fetch %.0f drain %.0f wait+compare %.0f "
             "chain-pre %.0f chain-hops %.0f chain-post %.0f repair %.0f\n", r / nb, h[0] / r, h[1] / r, h[2] / r, h[3] / r,
             h[4] / r, h[5] / r, h[6] / r, h[7] / r);
