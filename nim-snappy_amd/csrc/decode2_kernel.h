@@ -25,9 +25,10 @@
 //           its masked CRC32C from the window.
 //
 // One workgroup barrier per step separates "list k is complete" from "list k is consumed".
-// What bounds a step is two chains of dependent LDS round trips side by side (the front end's trips,
-// the resolvers' preparations and turns), not instruction issue or LDS bandwidth; their instructions
-// run at raised wave priority.  A unit that is one literal is copied HBM to HBM and never gets here.
+// A step is two chains of dependent LDS round trips side by side (the front end's trips, the resolvers'
+// preparations and turns; their instructions run at raised wave priority); with three workgroups on a CU the
+// chains hide behind each other and what the kernel is bound by is instructions and LDS operations per output
+// byte (ablation in profiles/README.md).  A unit that is one literal is copied HBM to HBM and never gets here.
 // Workgroup i takes unit order[i] (units of similar compressed length run next to each other).
 //
 // The inner loops are written branch-free: a lane that has nothing to store stores to a sink
