@@ -453,31 +453,26 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         uint32_t t, m;
         for (;;) {
           {
-            uint64_t tmp;
             asm volatile(
                 "1:\n"
                 "s_and_b32 %[t], %[x], 0xff\n"
                 "s_bfe_u32 %[m], %[x], 0x80008\n"
                 "s_cmp_lt_u32 %[t], 63\n"
                 "s_cbranch_scc0 2f\n"
-                "s_lshl_b64 %[tmp], 1, %[e]\n"
-                "s_or_b64 %[E], %[E], %[tmp]\n"
-                "s_lshl_b64 %[tmp], 1, %[m]\n"
-                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_bitset1_b64 %[E], %[e]\n"
+                "s_bitset1_b64 %[MS], %[m]\n"
                 "s_mov_b32 %[e], %[t]\n"
                 "s_bfe_u32 %[t], %[x], 0x80010\n"
                 "s_lshr_b32 %[m], %[x], 24\n"
                 "s_cmp_lt_u32 %[t], 63\n"
                 "s_cbranch_scc0 2f\n"
-                "s_lshl_b64 %[tmp], 1, %[e]\n"
-                "s_or_b64 %[E], %[E], %[tmp]\n"
-                "s_lshl_b64 %[tmp], 1, %[m]\n"
-                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_bitset1_b64 %[E], %[e]\n"
+                "s_bitset1_b64 %[MS], %[m]\n"
                 "s_mov_b32 %[e], %[t]\n"
                 "v_readlane_b32 %[x], %[P], %[e]\n"
                 "s_branch 1b\n"
                 "2:\n"
-                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x), [tmp] "=&s"(tmp)
+                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x)
                 : [P] "v"(P)
                 : "scc");
           }
@@ -768,31 +763,26 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           // longer than its lane has looked (254), a copy that ends behind the round (63 ..).  (A taken branch costs a
           // lone wave about 25 cycles, a register read across lanes as much, a scalar instruction 5.)
           {
-            uint64_t tmp;
             asm volatile(
                 "1:\n"
                 "s_and_b32 %[t], %[x], 0xff\n"
                 "s_bfe_u32 %[m], %[x], 0x80008\n"
                 "s_cmp_lt_u32 %[t], 63\n"
                 "s_cbranch_scc0 2f\n"
-                "s_lshl_b64 %[tmp], 1, %[e]\n"
-                "s_or_b64 %[E], %[E], %[tmp]\n"
-                "s_lshl_b64 %[tmp], 1, %[m]\n"
-                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_bitset1_b64 %[E], %[e]\n"
+                "s_bitset1_b64 %[MS], %[m]\n"
                 "s_mov_b32 %[e], %[t]\n"
                 "s_bfe_u32 %[t], %[x], 0x80010\n"
                 "s_lshr_b32 %[m], %[x], 24\n"
                 "s_cmp_lt_u32 %[t], 63\n"
                 "s_cbranch_scc0 2f\n"
-                "s_lshl_b64 %[tmp], 1, %[e]\n"
-                "s_or_b64 %[E], %[E], %[tmp]\n"
-                "s_lshl_b64 %[tmp], 1, %[m]\n"
-                "s_or_b64 %[MS], %[MS], %[tmp]\n"
+                "s_bitset1_b64 %[E], %[e]\n"
+                "s_bitset1_b64 %[MS], %[m]\n"
                 "s_mov_b32 %[e], %[t]\n"
                 "v_readlane_b32 %[x], %[P], %[e]\n"
                 "s_branch 1b\n"
                 "2:\n"
-                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x), [tmp] "=&s"(tmp)
+                : [E] "+s"(E), [MS] "+s"(MS), [e] "+s"(e), [t] "=&s"(t), [m] "=&s"(m), [x] "+s"(x)
                 : [P] "v"(P)
                 : "scc");
           }
