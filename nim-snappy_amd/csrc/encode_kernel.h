@@ -181,6 +181,14 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       return;
     }
     bool want_flush = false;
+    // (the rare items, all six in one LDS trip; they are used up -- or kept in these registers -- until the loop ends)
+    uint32_t c_lit_from, c_lit_len, c_cp_off, c_cp_len, c_lit2_from, c_lit2_len;
+    {
+      wave_fence();
+      const uint32_t cw = s_cold[lane & 7];
+      c_lit_from = readlane(cw, 0), c_lit_len = readlane(cw, 1), c_cp_off = readlane(cw, 2), c_cp_len = readlane(cw, 3);
+      c_lit2_from = readlane(cw, 4), c_lit2_len = readlane(cw, 5);
+    }
     for (;;) {
       if (want_flush || ofill > kObFlushAt) {  // (a step below adds at most 1 027 bytes)
         wave_fence();
@@ -200,13 +208,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         emit_round();
         continue;
       }
-      if (lit_len) {  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
-        const uint32_t from = lit_from, len = lit_len;
+      if (c_lit_len) {  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
+        const uint32_t from = c_lit_from, len = c_lit_len;
         if (len > 1024 && ofill) {  // a long literal goes from HBM to HBM, behind what is waiting
           want_flush = true;
           continue;
         }
-        lit_len = 0;
+        c_lit_len = 0;
         const uint32_t m = len - 1;
         const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
         const uint32_t t0 = m < 60 ? (m << 2) : (m < 256 ? (60u << 2) : (61u << 2));
@@ -240,8 +248,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         }
         continue;
       }
-      if (cp_len) {  // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
-        const uint32_t offset = cp_off, length = cp_len;
+      if (c_cp_len) {  // emitCopy, encoder.nim:81-125: 1 <= offset <= 65535, 4 <= length <= 65535
+        const uint32_t offset = c_cp_off, length = c_cp_len;
         if (length >= 68) {  // :97-103, up to 64 elements of 64 bytes per step
           const uint32_t k64 = (length - 68) / 64 + 1;
           const uint32_t c = k64 < 64 ? k64 : 64;
@@ -251,10 +259,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
             s_ob[ofill + 3 * lane + 2] = (uint8_t)(offset >> 8);
           }
           ofill += 3 * c;
-          cp_len = length - 64 * c;
+          c_cp_len = length - 64 * c;
           continue;
         }
-        cp_len = 0;
+        c_cp_len = 0;
         const bool two = length > 64;                      // :105-112
         const uint32_t r = two ? length - 60 : length;     // 4..64
         const bool c2 = r >= 12 || offset >= 2048;         // :114-125
@@ -269,10 +277,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         ofill += total;
         continue;
       }
-      if (lit2_len) {
-        lit_from = lit2_from;
-        lit_len = lit2_len;
-        lit2_len = 0;
+      if (c_lit2_len) {
+        c_lit_from = c_lit2_from;
+        c_lit_len = c_lit2_len;
+        c_lit2_len = 0;
         continue;
       }
       if (finished && ofill) {
@@ -281,6 +289,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
       break;
     }
+    if (lane < 8) s_cold[lane] = 0;  // (all used up)
+    wave_fence();
     cold_any = false;
   };
 
