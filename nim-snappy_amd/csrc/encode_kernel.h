@@ -546,16 +546,38 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint32_t llast = readlane(lens, mlast);
         dpend = true;
         dp_ms = MS;
-        if (llast > 64) {  // a long last copy goes the general way
-          dp_ms &= ~(1ull << mlast);
-          cp_off = base + mlast - readlane(cand, mlast);
-          cp_len = llast;
-          cold_any = true;
-        }
         dp_lit = !covered && lane >= 1u && lane < e;
         dp_len = lens;
         dp_off = p - cand;
         dp_byte = d & 0xff;
+        if (llast > 64) {
+          // A last copy of more than 64 bytes is several elements (emitCopy, encoder.nim:97-125: 64-byte copies while
+          // 68 or more are left, one of 60 if more than 64 are left then, the rest).  The lanes behind mlast lie
+          // inside this copy and have nothing to emit: lane mlast + j takes element j, as if a copy of that length
+          // started there -- the round's one prefix sum places them like any other element.  (More elements than
+          // lanes left: the general way.)
+          const uint32_t off_l = base + mlast - readlane(cand, mlast);
+          const uint32_t k64 = llast >= 68 ? (llast - 68) / 64 + 1 : 0;
+          const uint32_t rem = llast - 64 * k64;                 // 4..67
+          const uint32_t has60 = rem > 64 ? 1u : 0u;
+          const uint32_t nel = k64 + has60 + 1;
+#ifndef ENC_NO_LONG_SPLIT
+          if (mlast + nel <= 64) {
+            const uint32_t j = lane - mlast;                       // (lanes below mlast: huge)
+            const uint32_t lj = j < k64 ? 64u : ((j == k64) & (has60 != 0) ? 60u : rem - 60 * has60);
+            const bool mine_el = j < nel;
+            dp_len = mine_el ? lj : dp_len;
+            dp_off = mine_el ? off_l : dp_off;
+            dp_ms |= (nel >= 64 ? ~0ull : ((1ull << nel) - 1)) << mlast;
+          } else
+#endif
+          {
+            dp_ms &= ~(1ull << mlast);
+            cp_off = off_l;
+            cp_len = llast;
+            cold_any = true;
+          }
+        }
       }
       tick(7);
       next_emit = base + e;
