@@ -303,6 +303,23 @@ def test_long_same_offset_runs_inside_a_block(hip, orc):
         assert hip.decode_all_tags(body, 65536) == (0, src[:65536]), (period, seg)
 
 
+def test_copies_longer_than_a_round_at_every_lane(hip, orc):
+    """a match of 65..1100 bytes that starts at any of a round's 64 positions: the encoder emits the
+    64- / 60-byte elements of emitCopy (encoder.nim:97-125) from the idle lanes behind the match, or
+    -- more elements than lanes left -- through its slow drain; either way the oracle's bytes"""
+    rng = random.Random(65)
+    text = golden_file("alice29.txt")
+    for trial in range(24):
+        parts = [text[:3000 + trial]]
+        for k in range(40):
+            L = rng.choice((65, 66, 67, 68, 69, 100, 127, 128, 129, 131, 190, 192, 196, 260, 700, 1100))
+            at = rng.randrange(0, len(parts[0]) - L)
+            parts.append(parts[0][at:at + L])                       # a repeat: one long match
+            parts.append(rng.randbytes(rng.randrange(1, 70)))         # literals: shifts the next match's lane
+        src = b"".join(parts)[:65536]
+        assert hip.encode(src) == orc.encode(src), trial
+
+
 def test_stream_adapters(hip):
     """the batching stream front-ends (snappy/faststreams.nim, snappy/streams.nim restated in
     nim-snappy_amd/streams.py) over the HIP codec: same checks as with the oracle backend"""
