@@ -46,6 +46,28 @@ def test_model_equals_oracle_on_patterns_and_edges(orc):
     assert em.encode_block((s * 9)[:6000]) == _oracle_block(orc, (s * 9)[:6000])
 
 
+def test_model_splits_long_last_copies_over_the_lanes_behind_them(orc):
+    """the kernel's hand-over of a last copy of more than 64 bytes (lane mlast + j emits element j): same bytes as
+    emitCopy's loop, on data with matches of 65..1100 bytes at every lane of a round"""
+    import random
+    import encode_model as em
+    rng = random.Random(65)
+    text = golden_file("alice29.txt")
+    split = 0
+    for trial in range(6):
+        parts = [text[:3000 + trial]]
+        for _ in range(30):
+            L = rng.choice((65, 66, 67, 68, 69, 100, 127, 128, 129, 131, 190, 192, 196, 260, 700, 1100))
+            at = rng.randrange(0, len(parts[0]) - L)
+            parts.append(parts[0][at:at + L])
+            parts.append(bytes(rng.randrange(256) for _ in range(rng.randrange(1, 70))))
+        src = b"".join(parts)[:20000]
+        st = {}
+        assert em.encode_block(src, st) == _oracle_block(orc, src), trial
+        split += st.get("long_split", 0)
+    assert split >= 20
+
+
 @pytest.mark.parametrize("R", [128, 256])
 def test_wide_round_model_equals_oracle(orc, R):
     """tools/encode2_model.py: rounds of R = 128 / 256 consecutive positions (what several waves on one block

@@ -219,6 +219,26 @@ def encode_block(data, stats=None, wide=None):
                 hi = min(e, 64)
                 LIT = sum(1 << i for i in range(lo, hi) if not (COVER >> i) & 1)
                 sizes, chunks = [0] * 64, [b""] * 64
+                # A last copy of more than 64 bytes is several elements (emitCopy, encoder.nim:97-125).  Like the kernel's
+                # common-round loop: lane mlast + j emits element j as a copy of at most 64 bytes that "starts" there (the
+                # lanes behind mlast lie inside the copy and have nothing else to emit); more elements than lanes left:
+                # the one call of _emit_copy below (the kernel's slow drain).
+                elen, eoff, EMS = list(lens), [p[i] - cand[i] for i in range(64)], MS
+                mlast = MS.bit_length() - 1
+                if lens[mlast] > 64:
+                    ll = lens[mlast]
+                    k64 = (ll - 68) // 64 + 1 if ll >= 68 else 0
+                    rem = ll - 64 * k64
+                    has60 = 1 if rem > 64 else 0
+                    nel = k64 + has60 + 1
+                    if mlast + nel <= 64:
+                        if stats is not None:
+                            stats["long_split"] = stats.get("long_split", 0) + 1
+                        for j in range(nel):
+                            elen[mlast + j] = 64 if j < k64 else (60 if j == k64 and has60 else rem - 60 * has60)
+                            eoff[mlast + j] = p[mlast] - cand[mlast]
+                            assert not (LIT >> (mlast + j)) & 1
+                        EMS |= ((1 << nel) - 1) << mlast
                 for i in range(64):
                     if (LIT >> i) & 1:
                         rs = i == 0 or not (LIT >> (i - 1)) & 1
@@ -231,9 +251,9 @@ def encode_block(data, stats=None, wide=None):
                                 b += bytes([60 << 2, rl - 1])
                         b.append(data[p[i]])
                         chunks[i] = bytes(b)
-                    elif (MS >> i) & 1:
+                    elif (EMS >> i) & 1:
                         b = bytearray()
-                        _emit_copy(b, p[i] - cand[i], lens[i])
+                        _emit_copy(b, eoff[i], elen[i])
                         chunks[i] = bytes(b)
                 for i in range(64):
                     out += chunks[i]
