@@ -560,6 +560,11 @@ def self_launch(args, argv):
     does), relay rank 0's JSON line, exit with the child's code."""
     import socket
     import subprocess
+    # (counting devices does not touch the GPU on this image: a clear refusal instead of N - M ranks dying in set_device)
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("BENCH_SHARE_DEVICE"):
+        sys.stderr.write("bench.py: --gpus %d, but this node shows %d GPU(s)\n" % (args.gpus, have))
+        sys.exit(2)
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
