@@ -65,6 +65,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
   constexpr uint32_t kWin = kWinSize;
   __shared__ uint32_t s_cold[8];             // the rarely pending output items (see below)
+#ifndef ENC_NO_CMPST_WALK
+  __shared__ uint32_t s_walk;                // the lane the chain stands at (walked by one ds_cmpst)
+#endif
   __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
   __shared__ uint16_t s_seq_step[kSeqLen];
 
@@ -455,6 +458,47 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint32_t mv = cnd ? ctz64(cnd) : 64;
         const uint32_t lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(mv << 2), (int)(eq | (eq == 16 ? 0x100u : 0u)));
         const uint32_t nxt = mv == 64 ? 255u : ((lm & 0x100u) ? 254u : mv + lm);
+#ifndef ENC_NO_CMPST_WALK
+        // No match of the round fills its 16 bytes (92 % of text's rounds): nothing on the chain needs a look at
+        // memory, and ONE LDS instruction walks it -- every lane offers "if the chain stands at me, it goes on to
+        // where my copy ends"; the lanes of one address are served in ascending lane order and the pointers lead
+        // forward, so the word runs through the whole chain while the instruction executes, and a lane that gets
+        // back its own number was on it.  (Lane 63 never offers: a copy that ends there ends the round.)
+        // The order of service is not documented: out of order the word stops early, at a lane inside the round
+        // (it only ever moves along the chain), which is seen at once -- the loop below then does the round.
+        const bool walk_lds = (m4 & ballot(eq == 16)) == 0;
+        bool walked = false;
+        if (walk_lds) {
+          const uint32_t wa_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_walk;
+          uint32_t ret, fin;
+          if (lane == 0) s_walk = 1;
+          wave_fence();
+          asm volatile("ds_cmpst_rtn_b32 %0, %2, %3, %4\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(ret), "=&v"(fin)
+                       : "v"(wa_), "v"(lane == 63 ? 0xffffffffu : lane), "v"(nxt)
+                       : "memory");
+          const uint64_t ON = ballot((ret == lane) & (lane != 63));  // the copy ends the chain went on from (lane 1 among them)
+          const uint32_t f = readfirst(fin);
+          if (__builtin_expect(f >= 63, 1)) {
+            walked = true;
+            const uint32_t last = 63 - (uint32_t)__builtin_clzll(ON);
+            if (f == 255) {  // nothing found from the last of them: the round ends there
+              E = ON & ~(1ull << last);
+              e = last;
+            } else {         // a copy that ends at lane 63 or behind the round
+              E = ON;
+              e = f;
+            }
+            // the matches taken: a copy starts at me iff the match found from the nearest end at or below me is me
+            const uint64_t eb = E & ((2ull << lane) - 1);
+            const uint32_t ce = 63 - (uint32_t)__builtin_clzll(eb | 1ull);
+            const uint32_t mvc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ce << 2), (int)mv);
+            MS = ballot((eb != 0) & (mvc == lane));
+            tick(4);
+          }
+        }
+        if (!walked) {
+#endif
         const uint32_t pk = nxt | (mv << 8);
         const uint32_t pk2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nxt & 63) << 2), (int)pk);
         const uint32_t P = pk | (pk2 << 16);
@@ -499,6 +543,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           if (e > 62) break;
           x = readlane(P, e);
         }
+#ifndef ENC_NO_CMPST_WALK
+        }
+#endif
         tick(5);
       }
       bool covered = false, in_s = false;
