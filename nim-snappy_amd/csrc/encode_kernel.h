@@ -143,6 +143,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     __device__ __forceinline__ ColdU32& operator=(const ColdU32& o) { return *this = (uint32_t)o; }  // (the value, not the slot)
   };
   if (lane < 8) s_cold[lane] = 0;
+#ifndef ENC_NO_CMPST_WALK
+  if (lane == 0) s_walk = 1;
+#endif
   wave_fence();
   bool cold_any = false;                // one of (2)-(4) is set
   ColdU32 lit_from{&s_cold[0]}, lit_len{&s_cold[1]};    // (2) one literal ...
@@ -471,11 +474,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         if (walk_lds) {
           const uint32_t wa_ = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_walk;
           uint32_t ret, fin;
-          if (lane == 0) s_walk = 1;
           wave_fence();
-          asm volatile("ds_cmpst_rtn_b32 %0, %2, %3, %4\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+          // (the word is 1 -- every chain starts at lane 1 -- when a round begins: put back right behind the look at it)
+          asm volatile("ds_cmpst_rtn_b32 %0, %2, %3, %4\n\tds_read_b32 %1, %2\n\tds_write_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(ret), "=&v"(fin)
-                       : "v"(wa_), "v"(lane == 63 ? 0xffffffffu : lane), "v"(nxt)
+                       : "v"(wa_), "v"(lane == 63 ? 0xffffffffu : lane), "v"(nxt), "v"(1u)
                        : "memory");
           const uint64_t ON = ballot((ret == lane) & (lane != 63));  // the copy ends the chain went on from (lane 1 among them)
           const uint32_t f = readfirst(fin);
