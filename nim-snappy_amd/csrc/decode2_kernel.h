@@ -46,6 +46,8 @@ namespace snappy_hip {
 #endif
 constexpr uint32_t kD2Threads = D2_THREADS;  // waves 0,1: front end; waves 2..: resolvers
 constexpr uint32_t kD2Pool = kD2Threads / 64 - 2;
+constexpr uint32_t kFeWaves = 2;   // a step's stream (2 KiB) is parsed by the first two waves,
+constexpr uint32_t kFeTrips = 4;   // 256 bytes per trip, four trips each
 constexpr uint32_t kD2Ring = 4096;
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
 constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
@@ -91,6 +93,7 @@ struct Decode2Params {
   const uint32_t* crc_col;  // CrcParams::col_mul
   uint32_t crc_k32k;        // x^(8 * 32768) mod P: advances a CRC register over 32 KiB
   const uint32_t* order;    // workgroup i takes unit order[i] (nullptr: unit i)
+  const uint16_t* tag_lut;  // kTagLut in device memory: what a tag byte says about its element (see the front end)
 };
 
 // Branch-free element decode (decoder.nim:42-109); no validity checks, the index pass did them.
@@ -172,7 +175,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // threads 256..511 take the rows the flush has just completed, their column registers live across the steps.
 // The framed stream (uncompressFramed, snappy.nim:231) then decodes on the ring kernel too.
 template <uint32_t WIN, bool RCRC = false>
-__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode_indexed_kernel(Decode2Params prm) {
+__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 * 3 + 3) / 4 : 1) void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
   static_assert(RING || !RCRC, "the whole-block instantiation checksums its window at the end");
   constexpr uint32_t kOutSink = WIN;
@@ -185,7 +188,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   uint8_t* const s_out = RING ? s_static_window : s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave
-  __shared__ __attribute__((aligned(16))) uint16_t s_r16[kD2Pool][kGroup];
+  constexpr uint32_t kPool = kD2Pool;
+  constexpr uint32_t kPoolFirst = kFeWaves;  // first wave that resolves
+  __shared__ __attribute__((aligned(16))) uint16_t s_r16[kPool][kGroup];
   // element lists of the current and the previous step, in stream order
   // (one dword per element: low half the copy offset, 0 = literal; high half its first output byte -- the
   // front end writes an entry with one store)
@@ -200,6 +205,10 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
   __shared__ uint32_t s_runbad;                          // the unit is not one literal + copies of one offset
   __shared__ uint32_t s_rcrc_tab[RCRC ? 1024 : 1];       // (ring + CRC) the four stride tables of the column scheme
+  // the front end's tag table: in LDS where there is room for it (two workgroups of the whole-block instantiation
+  // have 32 bytes to spare: it reads the table through the vector cache)
+  constexpr bool kLutInLds = RING;
+  __shared__ uint16_t s_lut[kLutInLds ? 256 : 2];
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63;
@@ -237,17 +246,19 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   const uint8_t* g0 = unit - shift0;
   const uint32_t q_end = (uint32_t)(((uint64_t)shift0 + n_all + 15) & ~15ull);
   const uint32_t n_regions0 = (n_all + kSub - 1) / kSub;  // (>= the regions of the tag stream; all inside the unit's index)
-  const bool fe = wave <= 1;                             // front-end waves
-  const uint32_t half = wave == 1 ? 1 : 0;               // which 1 KiB of the step is mine
-  uint4 rf[4];  // (wave 1) the ring's first 4 KiB
+  // The stream ring is kept by the LAST wave: its 256 bytes of a step are the only ones whose look-ahead (an element's
+  // bytes, a short literal's payload) reaches into the next step's bytes, which land in the ring at the start of
+  // the step -- the wave that reads them is the wave that stored them, and a wave's LDS operations execute in order.
+  const bool ringw = wave == kFeWaves - 1;
+  uint4 rf[4];  // (ring wave) the ring's first 4 KiB
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const uint32_t q = (lane + 64 * i) * 16;
     rf[i] = make_uint4(0, 0, 0, 0);
-    if (wave == 1 && q < q_end) rf[i] = *reinterpret_cast<const uint4*>(g0 + q);
+    if (ringw && q < q_end) rf[i] = *reinterpret_cast<const uint4*>(g0 + q);
   }
-  const uint32_t ie0 = half * 64 + lane < n_regions0 ? idx[half * 64 + lane] : 0;
-  const uint32_t io0 = (1 - half) * 64 + lane < n_regions0 ? idx[(1 - half) * 64 + lane] : 0;
+  const uint32_t ie0 = lane < n_regions0 ? idx[lane] : 0;            // the first step's index entries, regions 0..63
+  const uint32_t io0 = 64 + lane < n_regions0 ? idx[64 + lane] : 0;  // ... and 64..127
   const uint32_t sb0 = tid * 128 < n_regions0 ? idx[tid * 128] : 0;  // (kMaxSteps <= the workgroup's threads)
   static_assert(kMaxSteps <= kD2Threads, "one s_sbase entry per thread");
 
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   const uint32_t n_chunks = (n + kChunk - 1) / kChunk;   // 2 KiB steps
   const uint32_t n_regions = (n + kSub - 1) / kSub;       // 16-byte index entries
 
+  if (kLutInLds && tid < 256) s_lut[tid] = prm.tag_lut[tid];  // (visible after the barrier below)
   if (tid == 0) {
     s_front = 0;
     s_skip = 0;
@@ -336,70 +348,18 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   const uint32_t sink = kOutSink + lane * 4;
   uint16_t* const sink16 = reinterpret_cast<uint16_t*>(s_out + sink);
 
-  // Copy L (0 = nothing, <= 64) bytes to s_out[dst..].  rd(k) returns the k-th ALIGNED dword of
-  // the source counted from the dword that holds its first byte; sh = source address & 3.
-  // Unaligned LDS dword accesses cost ~10-20x an aligned one on gfx950 (tools/probes/
-  // lds_rates.hip), so sources are read as aligned dwords and re-aligned with a funnel shift,
-  // and the destination is written bytewise.
-  auto lean_copy = [&](uint32_t dst, auto rd, uint32_t sh, uint32_t L) {
-    const uint32_t sh8 = sh * 8;
-    uint32_t s0 = rd(0u), s1 = rd(1u), s2 = rd(2u);
-    uint32_t v0 = __funnelshift_r(s0, s1, sh8), v1 = __funnelshift_r(s1, s2, sh8);
-    // A byte's address is (it is mine ? the element's window address : my sink) + j: one select per byte, and
-    // the + j rides in the store's offset field.  (An element that runs over the ring's end -- one in a few
-    // thousand -- takes the form with a wrap per byte.)
-    const uint32_t b0 = wa(dst);
-    if (RING && __builtin_expect(ballot(L != 0 && b0 + L > WIN) != 0, 0)) {
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[L > j ? wa(dst + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[L > 4 + j ? wa(dst + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
-      for (uint32_t k = 8; ballot(L > k); k += 8) {
-        s0 = s2;
-        s1 = rd(k / 4 + 1);
-        s2 = rd(k / 4 + 2);
-        v0 = __funnelshift_r(s0, s1, sh8);
-        v1 = __funnelshift_r(s1, s2, sh8);
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++) s_out[L > k + j ? wa(dst + k + j) : sink + j] = (uint8_t)(v0 >> (8 * j));
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j++)
-          s_out[L > k + 4 + j ? wa(dst + k + 4 + j) : sink + j] = (uint8_t)(v1 >> (8 * j));
-      }
-      return;
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[(L > j ? b0 : sink) + j] = (uint8_t)(v0 >> (8 * j));
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) s_out[(L > 4 + j ? b0 : sink - 4) + 4 + j] = (uint8_t)(v1 >> (8 * j));
-    for (uint32_t k = 8; ballot(L > k); k += 8) {  // longer elements: 8 more bytes per trip
-      s0 = s2;
-      s1 = rd(k / 4 + 1);
-      s2 = rd(k / 4 + 2);
-      v0 = __funnelshift_r(s0, s1, sh8);
-      v1 = __funnelshift_r(s1, s2, sh8);
-      const uint32_t bk = b0 + k;
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[(L > k + j ? bk : sink) + j] = (uint8_t)(v0 >> (8 * j));
-#pragma unroll
-      for (uint32_t j = 0; j < 4; j++) s_out[(L > k + 4 + j ? bk : sink - 4) + 4 + j] = (uint8_t)(v1 >> (8 * j));
-    }
-  };
-  auto ring_al = [&](uint32_t q) -> uint32_t {  // aligned dword that holds stream byte q - shift
-    return *reinterpret_cast<const uint32_t*>(s_ring + (q & (kD2Ring - 1) & ~3u));
-  };
   // keeps the compiler from reordering LDS traffic across it; the hardware executes the LDS
   // operations of one wave in issue order, one instruction at a time for the whole CU
   auto cbar = [] { asm volatile("" ::: "memory"); };
 
-  auto fill_ring = [&](uint32_t step) {  // (wave 1) the 4 KiB of the stream that start with `step`
+  auto fill_ring = [&](uint32_t step) {  // (ring wave) the 4 KiB of the stream that start with `step`
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t q = step * kChunk + (lane + 64 * i) * 16;
       if (q < q_end) ring_store(q, *reinterpret_cast<const uint4*>(g0 + q));
     }
   };
-  if (wave == 1) {  // land what was fetched at the start
+  if (ringw) {  // land what was fetched at the start
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t q = (lane + 64 * i) * 16;
@@ -410,13 +370,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   // Index entries of the NEXT step (mine and the other front-end wave's) are fetched at the start
   // of a step and consumed at the start of the next one, before anything younger is issued, so
   // the wait for them never also waits for fresh loads.  Entries past the end read as "none".
-  const uint32_t none_end = kIdxNone | (total << 11);
+  const uint32_t none_end = idx_none(total);
   auto idx_at = [&](uint32_t r) -> uint32_t { return r < n_regions ? idx[r] : none_end; };
-  // (every wave executes these loads -- straight-line code keeps the compiler from copying the
-  // loaded registers, and thereby waiting for them, at the end of the front-end branch)
-  uint32_t ie_pref = half * 64 + lane < n_regions ? ie0 : none_end;
-  uint32_t io_pref = (1 - half) * 64 + lane < n_regions ? io0 : none_end;
-  if (tid <= n_chunks && tid < kMaxSteps) s_sbase[tid] = tid < n_chunks ? sb0 >> 11 : total;
+  uint32_t ie_pref = lane < n_regions ? ie0 : none_end;       // regions 0..63 of the step
+  uint32_t io_pref = 64 + lane < n_regions ? io0 : none_end;  // regions 64..127
+  if (tid <= n_chunks && tid < kMaxSteps) s_sbase[tid] = tid < n_chunks ? idx_first_dst(sb0) : total;
   __syncthreads();
 
   // ---- a unit that is one literal followed by copies that all have ONE offset (what encodeBlock
@@ -510,7 +468,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
   // rows that end at or below `to` (a position everything below which is final and still in the ring)
   auto crc_rows_to = [&](uint32_t to) {
     const uint32_t upto_row = (to + crc_pad) / 1024;  // rows [crc_row, upto_row) are complete
-    if (tid >= 256) {
+    if (tid >= 256 && tid < 512) {
       const uint32_t t = tid - 256;
       const uint32_t sh8 = (total & 3) * 8;  // byte phase of the columns' dwords (0 for whole blocks)
       const uint32_t* const o32 = reinterpret_cast<const uint32_t*>(s_out);
@@ -538,11 +496,18 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
     }
     crc_row = upto_row > crc_row ? upto_row : crc_row;
   };
+  // per-lane constants of the front end
+  const uint32_t fe_bp = (lane >> 2) * 4;     // ds_bpermute address of my region's index entry in a half's first trip
+  const uint32_t fe_nsh = (lane & 3) * 4;     // my quad's bits of the region's start mask
+  const uint32_t fe_q = lane * 4 + shift;     // ring position of my quad, counted from a trip's first byte
+  const uint32_t fe_q1 = (lane & 3) >= 1 ? 0xffffffffu : 0u, fe_q2 = (lane & 3) >= 2 ? 0xffffffffu : 0u;
   bool passed_on = false;
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (wave 1)
+  uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (ring wave)
 
   unsigned long long tm_work = 0, tm_bar = 0;             // DEBUG timers
+  unsigned long long tt_flush = 0, tt_fe = 0, tt_prep = 0, tt_wait = 0, tt_turn = 0;  // DEBUG: where a step's time goes
+  auto now = [&]() -> unsigned long long { return SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0ull; };
   uint32_t acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;    // DEBUG counters, flushed once per wave
   for (uint32_t s = 0; s <= n_chunks; s++) {
     if (s_err) break;  // set before the last barrier: every wave sees it here
@@ -554,9 +519,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       const uint32_t to = sk >> 16, from = sk & 0xffffu;
       if (s >= from && s < to) {
         s = to < n_chunks ? to : n_chunks;
-        if (wave == 1 && s < n_chunks) fill_ring(s);
-        ie_pref = idx_at(s * 128 + half * 64 + lane);
-        io_pref = idx_at(s * 128 + (1 - half) * 64 + lane);
+        if (ringw && s < n_chunks) fill_ring(s);
+        ie_pref = idx_at(s * 128 + lane);
+        io_pref = idx_at(s * 128 + 64 + lane);
         pq[0] = pq[1] = 0xffffffffu;  // nothing in flight for the ring
         __syncthreads();
       }
@@ -596,7 +561,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
     asm volatile("" ::"v"(ie_pref), "v"(io_pref), "v"(pre[0].x), "v"(pre[0].w), "v"(pre[1].x),
                  "v"(pre[1].w));
     const uint32_t ie = ie_pref, io_cur = io_pref;  // index entries of this step
-    if (wave == 1 && s < n_chunks) {
+    if (ringw && s < n_chunks) {
       // the ring slots of the previous step are free now: land the 2 KiB fetched meanwhile
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -604,92 +569,215 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
     }
     // next step's index entries and the 2 KiB of stream after the ring's contents
     // (the front-end waves only: the resolvers have no use for them)
-    if (fe) {
-      ie_pref = idx_at((s + 1) * 128 + half * 64 + lane);
-      io_pref = idx_at((s + 1) * 128 + (1 - half) * 64 + lane);
-      if (wave == 1) {
+    if (wave < kFeWaves) {
+      ie_pref = idx_at((s + 1) * 128 + lane);
+      io_pref = idx_at((s + 1) * 128 + 64 + lane);
+    }
+    if (ringw) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-          pq[i] = s * kChunk + kD2Ring + (lane + 64 * i) * 16;
-          const uint32_t qc = pq[i] < q_end ? pq[i] : 0;  // clamped: always a valid address
-          pre[i] = *reinterpret_cast<const uint4*>(g0 + qc);
-        }
+      for (int i = 0; i < 2; i++) {
+        pq[i] = s * kChunk + kD2Ring + (lane + 64 * i) * 16;
+        const uint32_t qc = pq[i] < q_end ? pq[i] : 0;  // clamped: always a valid address
+        pre[i] = *reinterpret_cast<const uint4*>(g0 + qc);
       }
     }
 
-    if (fe && s < n_chunks) {
+    const unsigned long long tq0 = now();
+    tt_flush += tq0 - tm0;
+    if (s < n_chunks && wave < kFeWaves && !(SNAPPY_DBG(prm) & 4)) {
       // =================================== front end ===========================================
-      // (the front end's trips and the resolvers' turns are the two chains a step waits for: their
-      // instructions go first; the preparation of later groups fills the gaps)
+      // Two waves, four trips each; a trip takes 256 bytes of the step's stream, four per lane ("quad").  The
+      // index says where the elements start, so nothing here is a walk and no trip waits for another: a quad
+      // holds at most two starts (an element is at least two bytes long), A and B; both are decoded at once (a
+      // 256-entry table by tag byte), their output positions are the region's first position plus a prefix
+      // sum of lengths over the region's four lanes, their list slots a prefix sum of start counts.  Literal
+      // payloads are stored by the lanes that hold the payload BYTES, in three runs per lane: what the last
+      // short literal of an earlier lane ("C": prefix maximum + one cross-lane read) leaves of its payload in my
+      // quad, A's payload bytes in my quad, B's.  Literals with length bytes (61 bytes and more) are copied by
+      // the whole wave straight from HBM.
+      // (The step is bound by the resolvers' chain of turns behind one group's preparation -- timers in
+      // profiles/README.md; the front end only has to stay off that path: two waves of it take about 2/3 of a step.)
       __builtin_amdgcn_s_setprio(3);
       const uint32_t buf = s & 1;
-      const uint32_t c0 = s * kChunk + half * (kChunk / 2);
-      const uint32_t e_off = ie & 63;
-      const bool had = e_off != kIdxNone;
-      const uint32_t nel = had ? (ie >> 6) & 31 : 0;  // elements that start in my region
-      const uint32_t onel = (io_cur & 63) != kIdxNone ? (io_cur >> 6) & 31 : 0;
-      uint32_t dst = ie >> 11;
-      uint32_t ctot, otot;
-      uint32_t slot = wave_excl_scan(nel, lane, &ctot);
-      (void)wave_excl_scan(onel, lane, &otot);
-      if (half) slot += otot;  // the first half's elements come first in the list
-      ctot += otot;            // elements of the whole step (<= kElemCap by the format)
-      if (wave == 0 && lane == 0) s_cnt[buf] = ctot;
       uint32_t* const el = s_el[buf];
-
-      const uint32_t rs = c0 + lane * kSub;
-      const uint32_t r_end = rs + kSub < n ? rs + kSub : n;
-      uint32_t pos = rs + e_off;
-      bool live = had && pos < n && !(SNAPPY_DBG(prm) & 4);
-      bool big = false;  // a literal longer than 64 bytes ends my region: done below
-      uint32_t big_dst = 0, big_len = 0, big_src = 0, big_slot = 0;
+      // ---- how many elements start in front of a trip's 256 bytes: one inclusive scan over both halves' counts
+      // (regions 0..63 in the low half of a dword, 64..127 in the high half) ----
+      uint32_t cscan = __builtin_popcount(idx_starts(ie)) | (__builtin_popcount(idx_starts(io_cur)) << 16);
+      cscan += dpp_mov0<0x111>(cscan);  // row_shr:1, 2, 4, 8
+      cscan += dpp_mov0<0x112>(cscan);
+      cscan += dpp_mov0<0x114>(cscan);
+      cscan += dpp_mov0<0x118>(cscan);
+      cscan += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cscan, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+      cscan += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cscan, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+      const uint32_t call = readlane(cscan, 63);
+      if (wave == 0 && lane == 0) s_cnt[buf] = (call & 0xffffu) + (call >> 16);  // (<= kElemCap by the format)
       bool bad = false;
-      // the tag and the four bytes after it are fetched one trip ahead: as soon as an element's
-      // size is known the next element's bytes are requested, before this one's stores are issued
-      uint32_t t0 = ring_al(pos + shift), t1 = ring_al(pos + shift + 4), t2 = ring_al(pos + shift + 8);
-      while (ballot(live)) {
-        acc_a++;
-        const uint32_t q = pos + shift;
-        const uint32_t w0 = __funnelshift_r(t0, t1, (q & 3) * 8), w1 = __funnelshift_r(t1, t2, (q & 3) * 8);
-        const uint32_t b14 = (w0 >> 8) | (w1 << 24);
-        bool is_copy;
-        uint32_t L, size, hdr, off;
-        decode_fast(w0 & 0xff, b14, &is_copy, &L, &size, &hdr, &off);
-        {
-          const uint32_t qn = q + (live ? size : 0);
-          cbar();
-          t0 = ring_al(qn);
-          t1 = ring_al(qn + 4);
-          t2 = ring_al(qn + 8);
-          cbar();
-        }
-        const bool cpy = live && is_copy;
-        const bool lit = live && !is_copy;
-        const bool bad_off = cpy && (off == 0 || off > dst);  // decoder.nim:112
-        bad = bad || bad_off;
-        // ---- the element's list entry, and its slot at the 256-byte boundary it covers (if any) --
-        const bool put = live && slot < kElemCap;
-        *(put ? el + slot : reinterpret_cast<uint32_t*>(sink16)) = ((cpy && !bad_off) ? (off & 0xffffu) : 0u) | (dst << 16);
-        const uint32_t mb = (dst + kGroup - 1) / kGroup;
-        const bool covers = live && mb * kGroup < dst + L;
-        *(covers ? s_gidx + (mb & (kMaxBlockLen / kGroup - 1)) : sink16) = (uint16_t)slot;
-        // ---- literal: payload of up to 8 bytes here, up to 64 in lean_copy's rare loop -----------
-        const uint32_t qs = q + hdr;
-        const uint32_t Lw = (lit && L <= 64 && !(SNAPPY_DBG(prm) & 1)) ? L : 0;  // bytes this lane writes
-        lean_copy(dst, [&](uint32_t k) { return ring_al(qs + 4 * k); }, qs & 3, Lw);
-        if (lit && L > 64) {
-          big = true;
-          big_dst = dst;
-          big_len = L;
-          big_src = pos + hdr;
-          big_slot = slot;
-        }
-        slot += live ? 1 : 0;
-        dst += live ? L : 0;
-        pos += live ? size : 0;
-        live = live && pos < r_end;
+#pragma unroll 1
+      for (uint32_t trip = 0; trip < kFeTrips; trip++) {
+      const uint32_t vw = wave * kFeTrips + trip;  // which 256 bytes of the step
+      uint32_t base, mine;
+      {
+        const uint32_t upto = readlane(cscan, trip * 16 + 15);                // regions of my half up to the trip's last
+        const uint32_t below = trip ? readlane(cscan, trip * 16 - 1) : 0u;    // ... and below its first
+        const uint32_t sh = wave * 16;
+        const uint32_t before_half = (below >> sh) & 0xffffu;
+        mine = ((upto >> sh) & 0xffffu) - before_half;
+        base = before_half + (wave ? (call & 0xffffu) : 0u);
       }
-      // long literals: whole wave, straight from HBM (at most one per region)
+      bool big = false;  // a literal with length bytes is my quad's last element: done below
+      uint32_t big_dst = 0, big_len = 0, big_src = 0, big_slot = 0;
+      if (mine) {  // (nothing starts in my 256 bytes: the payload of a long literal, or the stream's end)
+        acc_a++;
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(fe_bp + trip * 64), (int)(wave == 0 ? ie : io_cur));
+        const uint32_t nib = (idx_starts(ent) >> fe_nsh) & 15u;
+        const uint32_t rdst = ent >> 16;
+        const uint32_t xr = lane * 4;                        // my first byte, counted from the wave's
+        const uint32_t xw = s * kChunk + vw * 256;           // the trip's first byte: stream position
+        // my four bytes and the eight behind them (the ring position is not dword-aligned: four aligned
+        // dwords, three funnel shifts by a uniform amount; the ring's first 16 bytes are mirrored behind it)
+        const uint32_t* const ra = reinterpret_cast<const uint32_t*>(s_ring + ((fe_q + xw) & (kD2Ring - 1) & ~3u));
+        const uint32_t a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
+        const uint32_t sh8 = readfirst((shift & 3) * 8);
+        const uint32_t w0 = __funnelshift_r(a0, a1, sh8), w1 = __funnelshift_r(a1, a2, sh8), w2 = __funnelshift_r(a2, a3, sh8);
+        // ---- my (up to) two elements: A at byte bA, B at byte bB (4 = none) ----
+        const uint32_t nib2 = nib & (nib - 1);
+        const bool hasA = nib != 0, hasB = nib2 != 0;
+        const uint32_t bA = __builtin_ctz(nib | 16u), bB = __builtin_ctz(nib2 | 16u);
+        const uint32_t dA = __funnelshift_r(w0, w1, 8 * bA), dB = __funnelshift_r(w0, w1, 8 * bB);  // from the tag on
+        // tag table (decoder.nim:42-109; validity: the index pass): [0:7) length of the forms without length
+        // bytes, [8:11) a copy1's offset bits 8..10, bit 11 literal, bit 12 literal with length bytes, bit 13 copy4
+        uint32_t tA, tB;
+        if (kLutInLds) {
+          tA = hasA ? s_lut[dA & 0xffu] : 0u;
+          tB = hasB ? s_lut[dB & 0xffu] : 0u;
+        } else {
+          tA = hasA ? prm.tag_lut[dA & 0xffu] : 0u;
+          tB = hasB ? prm.tag_lut[dB & 0xffu] : 0u;
+        }
+        uint32_t LA = tA & 0x7fu, LB = tB & 0x7fu;
+        // offset: 1, 2 or 3 bytes behind the tag (none for a literal), a copy1's high bits from the table
+        uint32_t offA = __builtin_amdgcn_ubfe(dA, 8, (dA & 3u) * 8) | (tA & 0x700u);
+        uint32_t offB = __builtin_amdgcn_ubfe(dB, 8, (dB & 3u) * 8) | (tB & 0x700u);
+        const bool litA = (tA & 0x800u) != 0, litB = (tB & 0x800u) != 0;
+        const bool bigA = (tA & 0x1000u) != 0, bigB = (tB & 0x1000u) != 0;
+        uint32_t hdr_big = 1;
+        if (__builtin_expect(ballot(((tA | tB) & 0x3000u) != 0) != 0, 0)) {
+          // literals with length bytes (decoder.nim:54-75); a copy4's fourth offset byte (an offset of 2^24 and
+          // more is beyond any block: the element list holds 16 bits, so it is made 0 = invalid here)
+          const uint32_t hA = __funnelshift_r(w1, w2, 8 * bA), hB = __funnelshift_r(w1, w2, 8 * bB);  // bytes 4.. behind the tag
+          const uint32_t tg = bigB ? dB : dA;
+          const uint32_t lenlen = ((tg >> 2) & 63u) - 59;  // 1..4 where it applies
+          const uint32_t b14 = ((bigB ? dB : dA) >> 8) | ((bigB ? hB : hA) << 24);
+          const uint32_t m = 0xffffffffu >> (32 - 8 * ((lenlen & 7) ? (lenlen & 7) : 4));
+          const uint32_t Lb = (b14 & m) + 1;
+          LA = bigA ? Lb : LA;
+          LB = bigB ? Lb : LB;
+          hdr_big = 1 + (lenlen & 7);
+          if ((tA & 0x2000u) && ((hA & 0xffu) || (offA >> 16))) offA = 0;
+          if ((tB & 0x2000u) && ((hB & 0xffu) || (offB >> 16))) offB = 0;
+        }
+        // ---- output positions: the region's first one + the lengths in front of me in my region (4 lanes) ----
+        uint32_t dstA, dstB;
+        {
+          const uint32_t T = LA + LB;
+          const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T, 0x90 /* quad_perm:[0,0,1,2] */, 0xf, 0xf, false);
+          const uint32_t x1 = T + (s1 & fe_q1);
+          const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x1, 0x44 /* quad_perm:[0,1,0,1] */, 0xf, 0xf, false);
+          dstA = rdst + x1 + (s2 & fe_q2) - T;  // (x1 + s2 & q2: inclusive over the quad)
+          dstB = dstA + LA;
+        }
+        // ---- list slots: a prefix sum of the start counts ----
+        uint32_t slotA;
+        {
+          const uint32_t cnt = __builtin_popcount(nib);
+          uint32_t c = cnt;
+          c += dpp_mov0<0x111>(c);
+          c += dpp_mov0<0x112>(c);
+          c += dpp_mov0<0x114>(c);
+          c += dpp_mov0<0x118>(c);
+          c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x142, 0xa, 0xf, false);
+          c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x143, 0xc, 0xf, false);
+          slotA = base + c - cnt;
+        }
+        const uint32_t slotB = slotA + 1;
+        // ---- list entries; the slot at each 256-byte output boundary an element covers ----
+        {
+          const bool badA = hasA && !litA && offA - 1 >= dstA, badB = hasB && !litB && offB - 1 >= dstB;  // decoder.nim:112
+          bad = bad || badA || badB;
+          uint32_t* const sink32 = reinterpret_cast<uint32_t*>(sink16);
+          *(hasA ? el + slotA : sink32) = ((litA || badA) ? 0xffffu : offA) | (dstA << 16);  // (list value of a literal: 0xffff)
+          *(hasB ? el + slotB : sink32) = ((litB || badB) ? 0xffffu : offB) | (dstB << 16);
+          // (an element covers a boundary when its last byte and the byte in front of it lie in different groups)
+          const uint32_t eA = dstA + LA - 1, eB = dstB + LB - 1;
+          *((hasA && ((eA ^ (dstA - 1)) >= kGroup)) ? s_gidx + (eA / kGroup) : sink16) = (uint16_t)slotA;
+          *((hasB && ((eB ^ (dstB - 1)) >= kGroup)) ? s_gidx + (eB / kGroup) : sink16) = (uint16_t)slotB;
+        }
+        // ---- literal payloads ----
+        const bool shortA = litA && !bigA, shortB = litB && !bigB;
+        // what a lane hands on: its last element, if that is a short literal: (payload end, counted from the wave's
+        // first byte) << 16 | (output position - that count of the payload's first byte) & 0xffff; else 0
+        const uint32_t info_last = hasB ? (shortB ? ((xr + bB + 1 + LB) << 16) | ((dstB - (xr + bB + 1)) & 0xffffu) : 0u)
+                                        : (shortA ? ((xr + bA + 1 + LA) << 16) | ((dstA - (xr + bA + 1)) & 0xffffu) : 0u);
+        uint32_t infoC;
+        uint32_t last_lit;  // (uniform) 1 + the last lane whose last element is a short literal
+        {
+          uint32_t k = info_last ? lane + 1 : 0u;
+          auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+          k = mx(k, dpp_mov0<0x111>(k));
+          k = mx(k, dpp_mov0<0x112>(k));
+          k = mx(k, dpp_mov0<0x114>(k));
+          k = mx(k, dpp_mov0<0x118>(k));
+          k = mx(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x142, 0xa, 0xf, false));
+          k = mx(k, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k, 0x143, 0xc, 0xf, false));
+          last_lit = readlane(k, 63);
+          const uint32_t before = dpp_mov0<0x138>(k);  // wave_shr:1: the inclusive maximum of the lane before me
+          const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(before * 4 - 4), (int)info_last);
+          infoC = before ? got : 0u;
+        }
+        if (!(SNAPPY_DBG(prm) & 1)) {
+          auto wad = [&](uint32_t a) -> uint32_t { return RING ? (a & (WIN - 1)) : (a & 0xffffu); };
+          // C: bytes 0 .. min(bA, what is left of its payload) of my quad
+          {
+            const uint32_t pe = infoC >> 16;
+            const uint32_t left = pe > xr ? pe - xr : 0u;
+            const uint32_t nC = left < bA ? left : bA;
+            const uint32_t aC = xr + infoC;
+            s_out[0 < nC ? wad(aC) : sink] = (uint8_t)w0;
+            s_out[1 < nC ? wad(aC + 1) : sink + 1] = (uint8_t)(w0 >> 8);
+            s_out[2 < nC ? wad(aC + 2) : sink + 2] = (uint8_t)(w0 >> 16);
+            s_out[3 < nC ? wad(aC + 3) : sink + 3] = (uint8_t)(w0 >> 24);
+          }
+          // A: its payload bytes in my quad: behind its tag, in front of B's tag (or the quad's end)
+          {
+            const uint32_t room = bB - bA - 1;  // (bA <= 3 here; bB = 4 without a B)
+            const uint32_t nA = shortA ? (LA < room ? LA : room) : 0u;
+            const uint32_t v = w0 >> (8 * bA + 8);
+            s_out[0 < nA ? wad(dstA) : sink] = (uint8_t)v;
+            s_out[1 < nA ? wad(dstA + 1) : sink + 1] = (uint8_t)(v >> 8);
+            s_out[2 < nA ? wad(dstA + 2) : sink + 2] = (uint8_t)(v >> 16);
+          }
+          // B: one byte, when it starts at byte 2
+          s_out[(shortB && bB == 2) ? wad(dstB) : sink + 3] = (uint8_t)(w0 >> 24);
+          // the wave's last short literal may run on behind the wave's 256 bytes (by less than 60): one byte per lane
+          const uint32_t tl = last_lit ? readlane(info_last, last_lit - 1) : 0u;
+          if ((tl >> 16) > 256) {
+            const uint32_t xt = 256 + lane;
+            const uint8_t v = s_ring[(xw + xt + shift) & (kD2Ring - 1)];
+            s_out[xt < (tl >> 16) ? wad(xt + tl) : sink] = v;
+          }
+        }
+        if (__builtin_expect(ballot((hasA && bigA) || (hasB && bigB)) != 0, 0)) {
+          const bool bb = hasB && bigB;
+          big = bb || (hasA && bigA);
+          big_dst = bb ? dstB : dstA;
+          big_len = bb ? LB : LA;
+          big_src = xw + xr + (bb ? bB : bA) + hdr_big;
+          big_slot = bb ? slotB : slotA;
+        }
+      }
+
+
+      // long literals: whole wave, straight from HBM (at most one per lane)
       uint64_t bigs = ballot(big);
       while (bigs) {
         const uint32_t e = ctz64(bigs);
@@ -729,18 +817,21 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         }
         if (hd + body + lane < eL) s_out[wa(ed + hd + body + lane)] = in0[es + hd + body + lane];
       }
+      }  // trips
       if (ballot(bad) && lane == 0) s_err = 1;
       __builtin_amdgcn_s_setprio(0);
       acc_b += 1;
-    } else if (!fe && s >= 1 && !(SNAPPY_DBG(prm) & 2)) {
+    }
+    tt_fe += now() - tq0;
+    if (s >= 1 && wave >= kPoolFirst && !(SNAPPY_DBG(prm) & 2)) {
       // =================================== resolvers ===============================================
       const uint32_t buf = (s - 1) & 1;
       const uint32_t cb = readfirst(s_sbase[s - 1]), cn = readfirst(s_sbase[s]);
       const uint32_t count = readfirst(s_cnt[buf]);
       const uint16_t* const el16 = reinterpret_cast<const uint16_t*>(s_el[buf]);
-      auto o16 = [&](uint32_t e) -> uint32_t { return el16[2 * e]; };      // copy offset, 0 = literal
+      auto o16 = [&](uint32_t e) -> uint32_t { return el16[2 * e]; };      // copy offset, 0xffff = literal
       auto d16 = [&](uint32_t e) -> uint32_t { return el16[2 * e + 1]; };  // first output byte
-      uint16_t* const r16 = s_r16[wave - 2];
+      uint16_t* const r16 = s_r16[wave - kPoolFirst];
       const uint32_t gfirst = cb & ~(kGroup - 1);
       // a group in the middle of one long literal holds no copy (the front end flags the
       // boundaries such a literal covers); nobody works on it, the group before it publishes it
@@ -750,53 +841,65 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         return (a & 0x8000u) && gg + kGroup < cn && a == b2;
       };
       uint32_t front = cb;  // what I know of s_front
-      constexpr uint32_t B = kGroup / 64;  // bytes per lane (4 or 8): one or two aligned dwords
+      constexpr uint32_t B = kGroup / 64;  // bytes per lane: one aligned dword
+      static_assert(B == 4, "one dword per lane");
+      const uint32_t* const el32 = s_el[buf];
+      // (a group's first words -- who covers its first byte, whether the group behind it is inside a long literal --
+      // are requested while the group before it is worked on: one round trip less on the wave's path)
+      uint32_t g = gfirst + (wave - kPoolFirst) * kGroup;
+      uint32_t ge_raw = s_gidx[(g / kGroup) & (kMaxBlockLen / kGroup - 1)];
+      uint32_t gn_raw = s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
       // (an empty step has nothing to resolve -- and after a fast-forward its list is not even its own)
-      for (uint32_t g = gfirst + (wave - 2) * kGroup; g < cn && cb < cn; g += kD2Pool * kGroup) {
-        // (one round trip for the three words a group starts with: who covers its first byte, whether
-        // the group behind it is inside a long literal, how far the frontier is)
-        const uint32_t ge_raw = s_gidx[g / kGroup];
-        const uint32_t gn_raw = s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
-        const uint32_t fr_raw = __hip_atomic_load(&s_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        cbar();
+      for (; g < cn && cb < cn; g += kPool * kGroup) {
+        const unsigned long long tg0 = now();
         const uint32_t ge = g > cb ? readfirst(ge_raw) : 0;
         const uint32_t gnext = readfirst(gn_raw);
+        {
+          const uint32_t gm = (g + kPool * kGroup) / kGroup;
+          ge_raw = s_gidx[gm & (kMaxBlockLen / kGroup - 1)];
+          gn_raw = s_gidx[(gm + 1) & (kMaxBlockLen / kGroup - 1)];
+        }
         if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
         const uint32_t p = g + B * lane;
-        front = readfirst(fr_raw);
+        // (what I saw of the frontier at my last turn; it only grows)
         if (front > (g > cb ? g : cb)) continue;  // a run extension (below) has covered my group
-        // the element that covers byte g is E0 (none in the step's first group when it starts
-        // inside it)
-        const uint32_t E0 = g > cb ? (ge & 0x7fffu) : (g == cb ? 0u : 0xffffffffu);
-        // every element after E0 that starts inside the group writes its index (1 = E0 + 1, ...) at
-        // its first byte's slot of the scratch; "which element covers byte x" is then the largest
-        // index at or below x: a prefix maximum.  (Slot 0 cannot hold a start -- E0 covers byte g
-        // -- and serves as the sink of the lanes that have nothing to write.)
+        // E0: the element that covers byte g (the step's first element where the step starts inside the group or
+        // at its first byte).  From E0 on, every element that starts below the group's end writes its list value
+        // -- copy offset, or 0xffff for a literal -- at its first byte's slot of the scratch, E0 at slot 0; "what
+        // covers byte x" is then the last value at or below x: a prefix maximum over (slot + 1) << 16 | value.
+        const uint32_t E0 = g > cb ? (ge & 0x7fffu) : 0u;
         uint32_t* const r32 = reinterpret_cast<uint32_t*>(r16 + B * lane);  // my B slots
-#pragma unroll
-        for (uint32_t k = 0; k < B / 2; k++) r32[k] = 0;
+        r32[0] = 0;
+        r32[1] = 0;
         cbar();
-        for (uint32_t e = E0 + 1 + lane;; e += 64) {
-          const uint32_t d = e < count ? d16(e) : 0xffffffffu;
-          const bool in = d - g < kGroup;  // (d > g: the list is in output order)
-          r16[in ? d - g : 0] = (uint16_t)(e - E0);
-          if (ballot(in) != ~0ull) break;
+        uint32_t nbelow = 0;  // elements from E0 on that start below the group's end
+        for (uint32_t e = E0 + lane;; e += 64) {
+          const uint32_t v = e < count ? el32[e] : 0xffffffffu;
+          const uint32_t d = v >> 16;
+          const bool below = e < count && d < g + kGroup;
+          const uint32_t slot = d > g ? d - g : 0;  // (E0 may start below g)
+          *(below ? r16 + slot : sink16) = (uint16_t)v;
+          const uint64_t mb = ballot(below);
+          nbelow += (uint32_t)__builtin_popcountll(mb);
+          if (mb != ~0ull) break;
         }
         cbar();
-        uint32_t li[B];  // index (relative to E0) of the element that covers each of my bytes
-#pragma unroll
-        for (uint32_t k = 0; k < B / 2; k++) {
-          const uint32_t rv = r32[k];
-          li[2 * k] = rv & 0xffffu;
-          li[2 * k + 1] = rv >> 16;
+        uint32_t kj[B];  // (slot + 1) << 16 | value of the start at each of my bytes, 0 where none is
+        {
+          const uint32_t r0 = r32[0], r1 = r32[1];
+          cbar();
+          const uint32_t pos1 = (B * lane + 1) << 16;
+          kj[0] = (r0 & 0xffffu) ? (r0 & 0xffffu) | pos1 : 0u;
+          kj[1] = (r0 >> 16) ? (r0 >> 16) | (pos1 + (1u << 16)) : 0u;
+          kj[2] = (r1 & 0xffffu) ? (r1 & 0xffffu) | (pos1 + (2u << 16)) : 0u;
+          kj[3] = (r1 >> 16) ? (r1 >> 16) | (pos1 + (3u << 16)) : 0u;
         }
-        cbar();
-        li[0] = lane == 0 ? 0 : li[0];
 #pragma unroll
-        for (uint32_t j = 1; j < B; j++) li[j] = li[j] > li[j - 1] ? li[j] : li[j - 1];
-        uint32_t tot;  // elements that start inside the group
-        const uint32_t before = wave_excl_scan_max(li[B - 1], lane, &tot);
+        for (uint32_t j = 1; j < B; j++) kj[j] = kj[j] > kj[j - 1] ? kj[j] : kj[j - 1];
+        uint32_t kmax;
+        const uint32_t before = wave_excl_scan_max(kj[B - 1], lane, &kmax);
+        const uint32_t tot = nbelow;  // (element starts in the group, and E0)
         // my bytes that belong to this step: [lo, hi) of 0..B
         uint32_t rmask = (1u << B) - 1;
         if (g < cb || g + kGroup > cn) {  // only the step's first and last group are partial
@@ -810,9 +913,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
 #pragma unroll
         for (uint32_t j = 0; j < B; j++) {
           const bool in = (rmask >> j) & 1;
-          const uint32_t ei = E0 + (li[j] > before ? li[j] : before);
-          const uint32_t off = o16(in ? ei : 0);
-          cp[j] = in && off != 0;
+          const uint32_t off = (kj[j] > before ? kj[j] : before) & 0xffffu;
+          cp[j] = in && off != 0xffffu;
           offj[j] = cp[j] ? off : 0;
           sp[j] = p + j - offj[j];
           anyc = anyc || cp[j];
@@ -822,12 +924,12 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         // inside it, one group per trip, once it is my turn.  run_end = first byte after them.
         // (only groups of few, long elements are examined: tot = element starts in the group)
         uint32_t run_off = 0, run_end = 0;
-        if (__builtin_expect(tot <= kGroup / 32 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0, 0)) {
+        if (__builtin_expect(tot <= kGroup / 32 + 1 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0, 0)) {
 #pragma unroll
           for (uint32_t j = 0; j < B; j++) off_differs = off_differs || offj[j] != run_off;
           if (ballot(off_differs) == 0) {
             uint32_t R = cn;
-            for (uint32_t e = E0 + tot + 1 + lane;; e += 64) {  // elements after those of my group
+            for (uint32_t e = E0 + tot + lane;; e += 64) {  // elements after those of my group
               const uint32_t oo = e < count ? o16(e) : 0;
               const uint64_t mm = ballot(oo != run_off);
               if (mm) {
@@ -860,9 +962,15 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
               r32[k] = (cp[2 * k] ? sp[2 * k] : 0xffffu) | ((cp[2 * k + 1] ? sp[2 * k + 1] : 0xffffu) << 16);
             cbar();
             anydep = false;
+            // (the four reads go out together: left to itself the compiler reads, waits and evaluates byte by byte --
+            // four LDS round trips a round)
+            uint32_t tq[B];
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++) tq[j] = r16[dep[j] ? sp[j] - g : 0];
+            asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]));
 #pragma unroll
             for (uint32_t j = 0; j < B; j++) {
-              const uint32_t t = r16[dep[j] ? sp[j] - g : 0];
+              const uint32_t t = tq[j];
               const bool fin = t == 0xffffu;  // my source is a final byte of the group
               sp[j] = (dep[j] && !fin) ? t : sp[j];
               dep[j] = dep[j] && !fin && t >= g;
@@ -874,7 +982,10 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         }
         cbar();
         // (ring) sources that have left the window: from HBM, where they were written at least a step ago
-        // (device-scope loads: past this CU's vector cache, which may hold the line's older state)
+        // (device-scope loads: past this CU's vector cache, which may hold the line's older state).
+        // (Requested ahead of the pointer rounds, so that the trip to the L2 runs beside them: measured slower --
+        // four more registers alive across the rounds, and the compiler then waits for each of a round's four
+        // LDS reads on its own.)
         uint32_t far_m = 0, far_v = 0;
         if (RING) {
           bool fj[B];
@@ -885,12 +996,18 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
             anyfar = anyfar || fj[j];
           }
           if (__builtin_expect(ballot(anyfar) != 0, 0)) {
+            // (four loads in flight, every lane: the addresses are selected, not the loads -- the empty asm keeps
+            // the compiler from turning the selects into branches around the loads, each with its own wait)
+            uint32_t ix[B];
+#pragma unroll
+            for (uint32_t j = 0; j < B; j++) ix[j] = fj[j] ? sp[j] : 0;
+            asm volatile("" : "+v"(ix[0]), "+v"(ix[1]), "+v"(ix[2]), "+v"(ix[3]));
 #pragma unroll
             for (uint32_t j = 0; j < B; j++) {
-              const uint32_t b = __hip_atomic_load(gout + (fj[j] ? sp[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint32_t b = __hip_atomic_load(gout + ix[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               far_m |= fj[j] ? 0xffu << (8 * j) : 0;
               far_v |= fj[j] ? b << (8 * j) : 0;
-              sp[j] = fj[j] ? p + j : sp[j];  // (its window read below: anything inside the window)
+              sp[j] = fj[j] ? p + j : sp[j];  // (its window read in the turn: anything inside the window)
             }
           }
           // A run is extended inside the ring: its sources must still be there.  (Otherwise group by group,
@@ -931,6 +1048,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(ad), "+s"(front_after));
         if (RING) asm volatile("" : "+v"(far_m), "+v"(far_v));  // (the loads have landed before the wait)
         // ---- my turn: every group below mine has published, i.e. everything below g is final ------
+        const unsigned long long tg1 = now();
+        tt_prep += tg1 - tg0;
         const uint32_t expect = g > cb ? g : cb;
         // (from here to the publish this wave is, or is about to be, on the step's critical path)
         __builtin_amdgcn_s_setprio(3);
@@ -978,6 +1097,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
           cbar();
         }
 #endif
+        const unsigned long long tg2 = now();
+        tt_wait += tg2 - tg1;
         if (front > expect) {  // covered by a run extension meanwhile
           __builtin_amdgcn_s_setprio(0);
           continue;
@@ -1019,6 +1140,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
         cbar();
         if (lane == 0) __hip_atomic_store(&s_front, front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_s_setprio(0);
+        tt_turn += now() - tg2;
       }
     }
     const unsigned long long tm1 = SNAPPY_STATS(prm) ? __builtin_amdgcn_s_memtime() : 0;
@@ -1032,8 +1154,13 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
       tm_bar += __builtin_amdgcn_s_memtime() - tm1;
     }
   }
-  if (SNAPPY_STATS(prm) && lane == 0 && (wave == 0 || wave == 2)) {  // DEBUG
-    unsigned long long* st = prm.stats + (wave == 0 ? 0 : 8);
+  if (SNAPPY_STATS(prm) && lane == 0 && (wave == 0 || wave == 5)) {  // DEBUG
+    unsigned long long* st = prm.stats + (wave == 0 ? 0 : 12);
+    atomicAdd(&st[6], tt_flush);
+    atomicAdd(&st[7], tt_fe);
+    atomicAdd(&st[8], tt_prep);
+    atomicAdd(&st[9], tt_wait);
+    atomicAdd(&st[10], tt_turn);
     atomicAdd(&st[0], (unsigned long long)acc_a);
     atomicAdd(&st[1], (unsigned long long)acc_b);
     atomicAdd(&st[2], (unsigned long long)acc_c);
@@ -1064,9 +1191,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? 6 : 1) void decode
     }
     if (do_crc) {  // the rows the loop has not seen, then the columns together (crc_pack_kernels.h)
       crc_rows_to(total);
-      uint32_t part = tid >= 256 ? crc_reg : 0;
+      uint32_t part = (tid >= 256 && tid < 512) ? crc_reg : 0;
       for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
-      if (lane == 0 && wave >= 4) {
+      if (lane == 0 && wave >= 4 && wave < 8) {
         atomicXor(&s_crc_acc, part);
         cbar();
         if (atomicAdd(&s_crc_cnt, 1u) == 3) {  // the last of the four waves: every part is in

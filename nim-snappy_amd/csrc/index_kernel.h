@@ -20,13 +20,15 @@
 //   3. A wave prefix sum of the per-region output byte counts gives every region its output
 //      position.
 //
-//   4. Each lane then walks its own region once more (one size-table read per element) to split
-//      its entry at the 16-byte boundary, so the decode kernel can give every 16 bytes of
-//      stream its own lane.
+//   4. Each lane then walks its own region once more, from its entry (the sizes of the elements at its
+//      32 positions are in eight registers), and marks every element start on the way.
 //
-// Index entry per 16 bytes of stream (u32):  [0:6) offset of the first element that starts in
-// them (32 = none)  [6:11) elements that start in them  [11:28) output position of that
-// first element.
+// Index entry per 16 bytes of stream (u32):  [0:16) bit k = an element starts at byte k of them;
+// [16:32) output position of the first such element (< 65536: an element writes at least one byte).
+// Where no element starts (the payload of a long literal): 0 in the low half, and the output position of
+// the next element MINUS ONE in the high half (the unit's total can be 65536; it is never 0 there: the
+// stream's first byte is an element start).  With the starts known, the decode kernel's front end is
+// position-parallel: no lane has to decode element k to find element k + 1.
 //
 // All input-side checks of decodeAllTags (truncated elements, the 61-byte rule of
 // decoder.nim:54-57, 4-byte length wrap :67-68, length bounds :77-79 / :127-128 through the
@@ -47,7 +49,11 @@ constexpr uint32_t kExitEnd = 0, kExitErr = 1;      // exit field: chain ended /
 constexpr uint32_t kExitFar = 896;                  // exit field >= 896: far exit = 896 + 32 * (length bytes - 1) + k
 constexpr uint32_t kOutSat = 0x1ffff - 1024;        // saturated element length (> 65536 = invalid); leaves
                                                     // room for the <= 16 x 64 bytes a region's chain adds on top
-constexpr uint32_t kIdxNone = 32;
+constexpr uint32_t kIdxNone = 32;                    // (region entry offset: no element starts in the region)
+// index entries (see above)
+__device__ __forceinline__ uint32_t idx_starts(uint32_t e) { return e & 0xffffu; }
+__device__ __forceinline__ uint32_t idx_first_dst(uint32_t e) { return (e >> 16) + ((e & 0xffffu) ? 0u : 1u); }  // of the first start at or behind the entry's bytes
+__device__ __forceinline__ uint32_t idx_none(uint32_t next_dst) { return (next_dst ? next_dst - 1 : 0u) << 16; }
 constexpr uint32_t kSub = 16;                       // stream bytes per index entry (half a region)
 constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's row in the size table
 // Longest tag stream the indexed path takes (a valid 64 KiB block needs at most 76 490 bytes,
@@ -219,9 +225,9 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   if (!SPLIT && n > kMaxFastIn) return finish(kNeedsOnePass, 0);  // (SPLIT: the host bounds n and the length)
   bool straddle = false;  // SPLIT: an element crosses a 64 KiB output boundary
 
-  // stream size of the element at each position.  (The block decoder's index walks positions 0..15 only -- to the
-  // first element at or behind byte 16 -- and keeps those 16 sizes in four registers: the pass is bound by how
-  // many waves fit a CU, and without this table a wave needs 8.75 KiB of LDS: 18 waves instead of 14.)
+  // stream size of the element at each position.  (The block decoder's index keeps the 32 sizes of a region in
+  // eight registers: the pass is bound by how many waves fit a CU, and without this table a wave needs 8.75 KiB
+  // of LDS: 18 waves instead of 14.)
   __shared__ uint8_t s_sz[SPLIT ? W * 64 * kSizeStride : 16];
 
   const uint32_t shift = (uint32_t)((uintptr_t)in0 & 15);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position
     const uint32_t ci = c0 / kChunk;
     uint32_t entry_off = kIdxNone, out_here = 0, nelem_here = 0;
-    uint32_t szp[4] = {0, 0, 0, 0};  // (block decoder's index) sizes of the elements at positions 0..15, a byte each
+    uint32_t szp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (block decoder's index) sizes of the elements at my 32 positions, a byte each
     // a verdict inside the loop: write it and, in SPLIT mode, stop the other waves
     auto bail = [&](uint32_t st) {
       finish(st, 0);
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         szb = ok ? szb : 255;
         s_tab[row + k] = t;
         if (SPLIT) s_sz[row8 + k] = (uint8_t)szb;
-        else if (k < (int)kSub) szp[k >> 2] |= szb << (8 * (k & 3));
+        else szp[k >> 2] |= szb << (8 * (k & 3));
       }
       };
       if (c0 + kChunk + 64 <= n) tabulate(std::true_type{});
@@ -476,31 +482,33 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         if (pos0 + out_here > B + kMaxBlockLen) straddle = true;
       }
     } else {
-    // ---- split my entry at the 16-byte boundary -------------------------------------------------
-    uint32_t e0 = kIdxNone, e1 = kIdxNone, nc0 = 0, nc1 = 0, pos1 = pos0 + out_here;
+    // ---- the element starts of my region: walk the chain from my entry, 16 positions at a time ------
+    uint32_t bm = 0;
     {
-      uint32_t pw = entry_off;  // walk to the first element at or after byte 16 (none = 32)
+      uint32_t pw = entry_off;  // (kIdxNone = 32: nothing starts here)
       while (ballot(pw < kSub)) {
         const uint32_t wv = pw < 4 ? szp[0] : (pw < 8 ? szp[1] : (pw < 12 ? szp[2] : szp[3]));
-        if (pw < kSub) pw += (wv >> ((pw & 3) * 8)) & 0xffu;
+        if (pw < kSub) {
+          bm |= 1u << pw;
+          pw += (wv >> ((pw & 3) * 8)) & 0xffu;
+          pw = rs + pw < n ? pw : kRegion;  // (the chain may end exactly at the stream's end: not an element)
+        }
       }
-      uint32_t out_second = 0, nc_second = 0;
-      if (entry_off != kIdxNone && pw < kRegion && rs + pw < n) {  // an element in the second half
-        const uint32_t t2 = s_tab[row + pw];
-        out_second = t_out(t2);
-        nc_second = t_nelem(t2);
-        e1 = pw - kSub;
-        nc1 = nc_second;
-        pos1 = pos0 + (out_here - out_second);
-      }
-      if (entry_off < kSub) {
-        e0 = entry_off;
-        nc0 = nelem_here - nc_second;
+      while (ballot(pw < kRegion)) {
+        const uint32_t wv = pw < 20 ? szp[4] : (pw < 24 ? szp[5] : (pw < 28 ? szp[6] : szp[7]));
+        if (pw < kRegion) {
+          bm |= 1u << pw;
+          pw += (wv >> ((pw & 3) * 8)) & 0xffu;
+          pw = rs + pw < n ? pw : kRegion;
+        }
       }
     }
+    // the first start of the second half writes at pos0 + (what the starts of the first half produce)
+    uint32_t pos1 = pos0 + out_here;  // (none there: the next element's position)
+    if (bm >> kSub) pos1 = pos0 + (out_here - t_out(s_tab[row + kSub + ctz64(bm >> kSub)]));
     if (rs < n) {
-      idx[2 * (rs / kRegion)] = e0 | (nc0 << 6) | (pos0 << 11);
-      idx[2 * (rs / kRegion) + 1] = e1 | (nc1 << 6) | (pos1 << 11);
+      idx[2 * (rs / kRegion)] = (bm & 0xffffu) ? (bm & 0xffffu) | (pos0 << 16) : idx_none(pos1);
+      idx[2 * (rs / kRegion) + 1] = (bm >> kSub) ? (bm >> kSub) | (pos1 << 16) : idx_none(pos0 + out_here);
     }
     }
     op += tot;
@@ -559,24 +567,20 @@ __global__ void verify_index_kernel(IndexParams prm, uint32_t* report) {
   const uint32_t nreg = (n + kSub - 1) / kSub;
   for (uint32_t r = 0; r < nreg; r++) {
     const uint32_t rs = r * kSub;
-    uint32_t want = kIdxNone | (dst << 11);
-    if (pos < rs + kSub && pos < n) {
-      uint32_t e_off = pos - rs, d0 = dst, nc = 0;
-      while (pos < rs + kSub && pos < n) {
-        uint32_t b = 0;
-        for (uint32_t i = 0; i < 4 && pos + 1 + i < n; i++) b |= (uint32_t)in0[pos + 1 + i] << (8 * i);
-        bool c;
-        uint32_t L, size, hdr, off;
-        decode_element(in0[pos], b, 0xffffffffu, &c, &L, &size, &hdr, &off);
-        nc += 1;
-        dst += L;
-        pos += size;
-      }
-      want = e_off | (nc << 6) | (d0 << 11);
+    uint32_t bm = 0, d0 = dst;
+    while (pos < rs + kSub && pos < n) {
+      uint32_t b = 0;
+      for (uint32_t i = 0; i < 4 && pos + 1 + i < n; i++) b |= (uint32_t)in0[pos + 1 + i] << (8 * i);
+      bool c;
+      uint32_t L, size, hdr, off;
+      decode_element(in0[pos], b, 0xffffffffu, &c, &L, &size, &hdr, &off);
+      bm |= 1u << (pos - rs);
+      dst += L;
+      pos += size;
     }
+    const uint32_t want = bm ? bm | (d0 << 16) : idx_none(dst);
     const uint32_t got = idx[r];
-    const bool same = (want & 63) == kIdxNone ? (got & 63) == kIdxNone : got == want;
-    if (!same) {
+    if (got != want) {
       report[u * 4] = r;
       report[u * 4 + 1] = want;
       report[u * 4 + 2] = got;

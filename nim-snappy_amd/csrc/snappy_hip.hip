@@ -117,6 +117,7 @@ struct snappy_hip_ctx {
   hipStream_t stream = nullptr;
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
+  uint16_t* d_tag_lut = nullptr;   // [256] the decode front end's tag table (decode2_kernel.h)
   uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
@@ -250,6 +251,19 @@ int ctx_init(snappy_hip_ctx* c) {
     c->crc_k32k = p;
   }
   build_probe_sequence(so.data(), ss.data());
+  {
+    // what a tag byte says about its element (decoder.nim:42-109): [0:7) length of the forms without length bytes,
+    // [8:11) a copy1's offset bits 8..10, bit 11 literal, bit 12 literal with length bytes, bit 13 copy4
+    uint16_t lut[256];
+    for (uint32_t tg = 0; tg < 256; tg++) {
+      const uint32_t hi6 = tg >> 2, ty = tg & 3;
+      const uint32_t len = ty == 1 ? 4 + (hi6 & 7) : 1 + hi6;
+      lut[tg] = (uint16_t)(len | (ty == 1 ? (tg & 0xe0u) << 3 : 0u) | (ty == 0 ? 0x800u : 0u) |
+                           ((ty == 0 && hi6 >= 60) ? 0x1000u : 0u) | (ty == 3 ? 0x2000u : 0u));
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_tag_lut, sizeof(lut)));
+    HIP_TRY(hipMemcpy(c->d_tag_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc((void**)&c->d_crc_tab, tab.size() * 4));
   HIP_TRY(hipMalloc((void**)&c->d_col_mul, mul.size() * 4));
   HIP_TRY(hipMalloc((void**)&c->d_seq_off, so.size() * 4));
@@ -299,6 +313,7 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_crc_tab);
   (void)hipFree(c->d_col_mul);
+  (void)hipFree(c->d_tag_lut);
   (void)hipFree(c->d_seq_off);
   (void)hipFree(c->d_seq_step);
   (void)hipFree(c->d_counters);
@@ -560,6 +575,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.idx = (const uint32_t*)d_idx;
     dp.n_units = n_units;
     dp.unit = unit;
+    dp.tag_lut = c->d_tag_lut;
     if (const char* e = dbg_env("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
     if (n_units >= 512 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
       void* d_perm;
@@ -578,8 +594,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     }
     unsigned long long* d_stats = nullptr;
     if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
-      HIP_TRY(hipMalloc((void**)&d_stats, 128));
-      HIP_TRY(hipMemsetAsync(d_stats, 0, 128, s));
+      HIP_TRY(hipMalloc((void**)&d_stats, 256));
+      HIP_TRY(hipMemsetAsync(d_stats, 0, 256, s));
       dp.stats = d_stats;
     }
     {
@@ -630,14 +646,18 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
              kD2DynWindow + ((dbg_env("SNAPPY_HIP_ONE_WG") || kD2Threads > 640) ? 8192 : 0) /* one per CU */, s, dp);
     }
     if (d_stats) {
-      unsigned long long h[16];
-      HIP_TRY(hipMemcpyAsync(h, d_stats, 128, hipMemcpyDeviceToHost, s));
+      unsigned long long h[32];
+      HIP_TRY(hipMemcpyAsync(h, d_stats, 256, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      const double st = h[1] ? (double)h[1] : 1.0;  // front-end steps (wave 0)
-      fprintf(stderr, "STATS front end: steps %llu trips/step %.2f work %.0f barrier %.0f ticks/step\n", h[1],
-              h[0] / st, h[4] / st, h[5] / st);
-      fprintf(stderr, "STATS resolver wave 2: groups/step %.2f doubling rounds/group %.2f work %.0f barrier %.0f ticks/step\n",
-              h[10] / st, h[10] ? (double)h[11] / h[10] : 0.0, h[12] / st, h[13] / st);
+      for (int w = 0; w < 2; w++) {  // waves 0 and 5 of every workgroup, summed
+        const unsigned long long* q = h + 12 * w;
+        const double st = q[1] ? (double)q[1] : 1.0;  // steps
+        fprintf(stderr,
+                "STATS wave %d: steps %llu; per step: groups %.2f doubling rounds/group %.2f | ticks: flush %.0f front end %.0f "
+                "prep %.0f wait %.0f turn %.0f barrier %.0f (work %.0f)\n",
+                w ? 5 : 0, q[1], q[2] / st, q[2] ? (double)q[3] / q[2] : 0.0, q[6] / st, q[7] / st, q[8] / st, q[9] / st,
+                q[10] / st, q[5] / st, q[4] / st);
+      }
       (void)hipFree(d_stats);
     }
   }
