@@ -205,9 +205,11 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
   __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
   __shared__ uint32_t s_runbad;                          // the unit is not one literal + copies of one offset
   __shared__ uint32_t s_rcrc_tab[RCRC ? 1024 : 1];       // (ring + CRC) the four stride tables of the column scheme
-  // the front end's tag table: in LDS where there is room for it (two workgroups of the whole-block instantiation
-  // have 32 bytes to spare: it reads the table through the vector cache)
-  constexpr bool kLutInLds = RING;
+  // the front end's tag table: in LDS where there is room for it.  (Two workgroups of the whole-block instantiation
+  // have 32 bytes to spare; three of the checksumming one fit a CU up to 53 760 bytes each -- LDS is handed out in
+  // pieces of 1 280 bytes: with the table, 53 976 bytes, only two fit and the kernel takes 9.5 ms instead of 7.9.
+  // Those two read the table through the vector cache.)
+  constexpr bool kLutInLds = RING && !RCRC;
   __shared__ uint16_t s_lut[kLutInLds ? 256 : 2];
 
   const uint32_t tid = threadIdx.x;
