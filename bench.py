@@ -377,104 +377,171 @@ def _host_room_bytes():
 
 def sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, total_blocks, requested_blocks):
     """BASELINE configs[4]: block-range sharded compress of a FIXED corpus (strong scaling) with the host-side
-    concatenate.  Rank r owns blocks split_range(r, world, total_blocks) (resident in its HBM before the timed
-    region), encodes them as framed chunks (encodeFrame, encoder.nim:385-426) and packs them; the ONE exchange is
-    an all_gather of the shard totals, whose exclusive scan (the reference's serial `written += ...`,
-    snappy.nim:56-62,146-153) places every shard in the ONE host buffer -- a /dev/shm mapping every rank has
-    page-locked -- and each rank's copy lands there over its own GPU's link.  No data-path collective."""
+    concatenate, in STAGES so that a GPU encodes while its earlier output travels.  With S = the stage size,
+    rank r owns the global block ranges [(j N + r) S, (j N + r + 1) S), j = 0, 1, ... (resident in its HBM before the
+    timed region): the stream is the stages in order, each the ranks in order -- the blocks in global order.  A rank
+    encodes a stage as framed chunks (encodeFrame, encoder.nim:385-426) and packs it; the ONE exchange per stage is
+    an all_gather of the N stage sizes, whose running sum (the reference's serial `written += ...`,
+    snappy.nim:56-62,146-153) places the stage in the ONE host buffer -- a /dev/shm mapping every rank has
+    page-locked -- and the rank's copy goes out on a second stream, over its own GPU's link, while the next stage is
+    encoded.  No data-path collective.  (snappy_hip_compress_shards_staged is the same from one process.)"""
     import mmap
     dd = dist if world > 1 else None
     cdev = dev if backend == "nccl" else None
-    lo, hi = shard.split_range(rank, world, total_blocks)
-    nbk = hi - lo
-    PIECE = 65536  # blocks per encode launch (4 GiB: the slots of one launch take 5 GB)
-    d_sh = torch.empty(nbk * BLOCK, dtype=torch.uint8, device=dev)
-    for b0 in range(0, nbk, 4096):
-        c = min(4096, nbk - b0)
-        d_sh[b0 * BLOCK:(b0 + c) * BLOCK] = corpus.make_blocks_torch(torch, lo + b0, c, dev).reshape(-1)
-    pc = min(PIECE, max(nbk, 1))
-    d_slots = torch.empty(pc * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
-    d_sizes = torch.empty(pc, dtype=torch.int32, device=dev)
-    d_offsets = torch.empty(pc + 1, dtype=torch.int64, device=dev)
+    S = max(1, min(16384, total_blocks // (2 * world)))  # stage: 1 GiB of input, at least two stages a rank
+    n_stages = -(-total_blocks // (S * world))
+    mine_b = []  # my block range of every stage (possibly empty in the last one)
+    for j in range(n_stages):
+        lo = min(total_blocks, (j * world + rank) * S)
+        mine_b.append((lo, min(total_blocks, lo + S)))
+    nbk = sum(hi - lo for lo, hi in mine_b)
+    d_sh = torch.empty(max(nbk, 1) * BLOCK, dtype=torch.uint8, device=dev)
+    at_b = 0
+    for lo, hi in mine_b:
+        for b0 in range(lo, hi, 4096):
+            c = min(4096, hi - b0)
+            d_sh[at_b * BLOCK:(at_b + c) * BLOCK] = corpus.make_blocks_torch(torch, b0, c, dev).reshape(-1)
+            at_b += c
+    d_slots = torch.empty(S * hip.SLOT_STRIDE, dtype=torch.uint8, device=dev)
+    d_sizes = torch.empty(S, dtype=torch.int32, device=dev)
+    d_offsets = torch.empty(S + 1, dtype=torch.int64, device=dev)
 
-    def encode_shard(d_packed):
-        """encode + pack every piece of the shard behind the one before it; returns the shard's bytes"""
-        at = 0
-        for b0 in range(0, nbk, PIECE):
-            c = min(PIECE, nbk - b0)
-            ctx.encode_blocks(d_sh[b0 * BLOCK:(b0 + c) * BLOCK], c * BLOCK, d_slots, d_sizes, unit=hip.UNIT_FRAME)
-            if d_packed is None:  # sizing pass: totals only
-                ctx.sync()
-                at += int(d_sizes[:c].to(torch.int64).sum().item())
-            else:
-                ctx.pack(d_slots, d_sizes, c, d_packed, d_offsets, base=at)
-                ctx.sync()
-                at = int(d_offsets[c].item())
-        return at
+    def exchange(size):
+        """the one exchange of a stage: N sizes"""
+        if world == 1:
+            return [size]
+        t = torch.tensor([size], dtype=torch.int64, device=cdev if cdev is not None else "cpu")
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [int(g.item()) for g in got]
 
-    def exchange(mine):
-        """the one exchange: N shard totals -> exclusive scan"""
-        totals = [mine]
-        if world > 1:
-            t = torch.tensor([mine], dtype=torch.int64, device=cdev if cdev is not None else "cpu")
-            got = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(got, t)
-            totals = [int(g.item()) for g in got]
-        offs = [10]
-        for v in totals:
-            offs.append(offs[-1] + v)
-        return totals, offs
+    def run(d_packed, host_t, copy_stream):
+        """every stage: encode + pack behind the stage before it, exchange the sizes, send the stage to its place in
+        the host buffer (when there is one) on the copy stream; returns the table of sizes [stage][rank]"""
+        table, at, in_b, base = [], 0, 0, 10
+        for lo, hi in mine_b:
+            c = hi - lo
+            end = at
+            if c:
+                ctx.encode_blocks(d_sh[in_b * BLOCK:(in_b + c) * BLOCK], c * BLOCK, d_slots, d_sizes, unit=hip.UNIT_FRAME)
+                if d_packed is None:  # sizing pass
+                    ctx.sync()
+                    end = at + int(d_sizes[:c].to(torch.int64).sum().item())
+                else:
+                    ctx.pack(d_slots, d_sizes, c, d_packed, d_offsets, base=at)
+                    ctx.sync()
+                    end = int(d_offsets[c].item())
+            sizes = exchange(end - at)
+            if host_t is not None and end > at:
+                off = base + sum(sizes[:rank])
+                with torch.cuda.stream(copy_stream):  # (the stage is complete: ctx.sync() above)
+                    host_t[off:off + end - at].copy_(d_packed[at:end], non_blocking=True)
+            base += sum(sizes)
+            table.append(sizes)
+            at, in_b = end, in_b + c
+        if copy_stream is not None:
+            copy_stream.synchronize()
+        return table
 
-    mine = encode_shard(None)  # warm-up + sizes (the encoding is deterministic)
-    totals0, offs0 = exchange(mine)
-    stream_len = offs0[-1]
+    table0 = run(None, None, None)  # warm-up + sizes (the encoding is deterministic)
+    mine = sum(row[rank] for row in table0)
+    stream_len = 10 + sum(sum(row) for row in table0)
+    totals0 = [sum(row[r] for row in table0) for r in range(world)]
     d_packed = torch.empty(mine + 64, dtype=torch.uint8, device=dev)
     # the ONE host buffer: a shared mapping, page-locked by every rank (the caller's output buffer of
-    # snappy_hip_compress_shards, here shared between processes)
+    # snappy_hip_compress_shards_staged, here shared between processes)
     path = "/dev/shm/snappy_bench_%s_%d.bin" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
-    if rank == 0:
-        with open(path, "wb") as fh:
-            fh.truncate(stream_len)
+    fh = mm = None
+    registered = []
+    try:
+        if rank == 0:
+            with open(path, "wb") as f0:
+                f0.truncate(stream_len)
+        if world > 1:
+            dist.barrier()
+        fh = open(path, "r+b")
+        mm = mmap.mmap(fh.fileno(), stream_len)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:  # every rank has it mapped: the name can go (nothing is left behind if a rank dies later)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        host = np.frombuffer(mm, dtype=np.uint8)
+        host_t = torch.from_numpy(host)
+        # my pieces of it: touched (shm pages are allocated on first touch) and page-locked
+        my_pieces, base = [], 10
+        for row in table0:
+            if row[rank]:
+                my_pieces.append((base + sum(row[:rank]), row[rank]))
+            base += sum(row)
+        if world == 1:
+            my_pieces = [(0, stream_len)]
+        pinned = bool(my_pieces)
+        for off, ln in my_pieces:
+            host_t[off:off + ln:4096] = 0
+            try:
+                ok = int(torch.cuda.cudart().cudaHostRegister(host_t[off:].data_ptr(), ln, 0)) == 0
+            except Exception:
+                ok = False
+            if ok:
+                registered.append(host_t[off:].data_ptr())
+            pinned = pinned and ok
+        if rank == 0:
+            host[:10] = np.frombuffer(bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]), dtype=np.uint8)
+        copy_stream = torch.cuda.Stream(device=dev)
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            table = run(d_packed, host_t, copy_stream)
+            torch.cuda.synchronize()
+            t_rank = time.perf_counter() - t0
+            assert table == table0, "stage sizes changed between two encodings"
+            if world > 1:
+                dist.barrier()
+            t = shard.max_over_ranks(dd, t_rank, cdev)
+            best = t if best is None else min(best, t)
+        res = _sharded_result(hip, ctx, corpus, rank, world, dev, total_blocks, requested_blocks, S, n_stages, table0,
+                              totals0, stream_len, mine, d_packed, d_slots, d_sizes, d_offsets, host, mm, best, pinned,
+                              lambda: run(d_packed, None, None))
+    finally:
+        for ptr in registered:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(ptr)
+            except Exception:
+                pass
+        host = host_t = None
+        if mm is not None:
+            try:
+                mm.close()
+            except BufferError:
+                pass
+        if fh is not None:
+            fh.close()
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
     if world > 1:
         dist.barrier()
-    fh = open(path, "r+b")
-    mm = mmap.mmap(fh.fileno(), stream_len)
-    host = np.frombuffer(mm, dtype=np.uint8)
-    my_off, my_len = offs0[rank], totals0[rank]
-    h_slice = torch.from_numpy(host[my_off:my_off + my_len]) if my_len else None
-    pinned = False
-    if my_len:
-        h_slice[::4096] = 0  # touch (shm pages are allocated on first touch)
-        try:
-            pinned = int(torch.cuda.cudart().cudaHostRegister(h_slice.data_ptr(), my_len, 0)) == 0
-        except Exception:
-            pinned = False
-    if rank == 0:
-        host[:10] = np.frombuffer(bytes([0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]), dtype=np.uint8)
-    best = None
-    for _ in range(2):
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        got = encode_shard(d_packed)
-        totals, offs = exchange(got)
-        assert totals == totals0 and offs == offs0, "shard totals changed between two encodings"
-        if my_len:
-            h_slice.copy_(d_packed[:my_len], non_blocking=True)
-        torch.cuda.synchronize()
-        t_rank = time.perf_counter() - t0
-        if world > 1:
-            dist.barrier()
-        t = shard.max_over_ranks(dd, t_rank, cdev)
-        best = t if best is None else min(best, t)
-    enc_only = None
+    del d_sh, d_slots, d_packed
+    return res
+
+
+def _sharded_result(hip, ctx, corpus, rank, world, dev, total_blocks, requested_blocks, S, n_stages, table0, totals0,
+                    stream_len, mine, d_packed, d_slots, d_sizes, d_offsets, host, mm, best, pinned, encode_again):
+    """rank 0: the stream's digest, the byte comparison with a single-GPU encoding, the result object"""
+    PIECE = 65536  # blocks per encode launch of the comparison (4 GiB: the slots of one launch take 5 GB)
+    pc = d_sizes.numel()
     ctx.timing(True)
-    encode_shard(d_packed)
-    enc_only = ctx.kernel_ms(1)[0]
+    encode_again()
+    enc_only = ctx.kernel_ms(1)[0]  # (average over the stages' launches)
     ctx.timing(False)
-    if pinned:
-        torch.cuda.cudart().cudaHostUnregister(h_slice.data_ptr())
     if world > 1:
         dist.barrier()
     res = None
@@ -519,18 +586,21 @@ def sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, tot
             equal = False
         u = total_blocks * BLOCK
         res = {
-            "what": "BASELINE configs[4]: block-range sharded compressFramed, N shard totals -> host scan -> every "
-                    "shard copied to its offset in ONE page-locked host buffer; fixed total (strong scaling)",
+            "what": "BASELINE configs[4]: block-range sharded compressFramed in stages (stage j of rank r = blocks "
+                    "[(j N + r) S, (j N + r + 1) S)): N stage sizes -> host scan -> the stage copied to its offset in ONE "
+                    "page-locked host buffer on a second stream while the next stage is encoded; fixed total (strong scaling)",
             "total_blocks": total_blocks,
             "uncompressed_bytes": u,
             "reduced_from_blocks": requested_blocks if requested_blocks != total_blocks else None,
             "stream_bytes": stream_len,
             "n_shards": world,
+            "stage_blocks": S,
+            "n_stages": n_stages,
             "shard_bytes": totals0,
-            "shard_offsets": offs0,
+            "stage0_sizes": table0[0],
             "seconds": round(best, 5),
             "strong_GBps": round(u / best / 1e9, 3),
-            "encode_kernel_ms_rank0": round(enc_only, 3),
+            "encode_kernel_ms_per_stage_rank0": round(enc_only, 3),
             "host_buffer_page_locked": pinned,
             "stream_sha256_tree64MiB": digest,  # sha256 of the sha256 digests of the stream's 64 MiB pieces
             # a single-GPU encoding of all blocks on rank 0, compared byte for byte with the host buffer
@@ -538,20 +608,6 @@ def sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, tot
         }
         if not res["equals_single_gpu_sha256"]:
             raise SystemExit("bench: the sharded stream differs from the single-GPU stream")
-    del host, h_slice
-    try:
-        mm.close()
-    except BufferError:
-        pass
-    fh.close()
-    if world > 1:
-        dist.barrier()
-    if rank == 0:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
-    del d_sh, d_slots, d_packed
     return res
 
 

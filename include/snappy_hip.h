@@ -176,6 +176,19 @@ int snappy_hip_uncompress_framed_d(snappy_hip_ctx* ctx, const uint8_t* d_in, uin
 int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
                                const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
                                uint64_t* written, uint64_t* shard_off);
+/* The same in STAGES of stage_blocks 64 KiB blocks per context, so that a GPU encodes while its earlier output
+ * travels (the reference's serial loop over slices, snappy.nim:56-62, :146-153, cut across the GPUs instead of along
+ * them): with S = stage_blocks, the global block range [(j n + k) S, (j n + k + 1) S) is stage j of context k, and
+ * d_in[k] holds context k's stages back to back (in_len[k] must be exactly what that layout gives context k of the
+ * total; the total's tail may leave the last stage short).  A context encodes + packs a stage, publishes its size,
+ * downloads -- on a second stream -- every earlier stage of its own whose place in `out` is known by then (the sum of
+ * all sizes in front of it: n integers per stage through host memory, the path's one exchange), and goes on with the
+ * next stage.  The downloads overlap the kernels when `out` is page-locked.  stage_blocks = 0: one stage, i.e.
+ * snappy_hip_compress_shards.  shard_off (may be NULL): n + 1 values, where each context's first stage lies and the
+ * stream's end.  The result is byte-identical to one call over the blocks in global order. */
+int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
+                                      const uint64_t* in_len, uint64_t stage_blocks, int framed, uint8_t* out,
+                                      uint64_t cap, uint64_t* written, uint64_t* shard_off);
 /* Batches of 512 units or more are launched in a sorted order (decode: by compressed length, longest first; encode:
  * by a sketch of the block), which costs three small launches and is worth ~10 % on mixed batches; results never
  * depend on it.  enable = 0 launches in the caller's order (default 1). */

@@ -46,7 +46,8 @@ ABI_SYMBOLS = [
     "snappy_hip_encode_blocks_d", "snappy_hip_pack_d", "snappy_hip_decode_blocks_d",
     "snappy_hip_crc32c_d", "snappy_hip_ctx_timing", "snappy_hip_ctx_kernel_ms",
     "snappy_hip_compress_framed_d", "snappy_hip_uncompress_framed_d", "snappy_hip_uncompress_d",
-    "snappy_hip_compress_shards", "snappy_hip_release_pool", "snappy_hip_ctx_launch_order",
+    "snappy_hip_compress_shards", "snappy_hip_compress_shards_staged", "snappy_hip_release_pool",
+    "snappy_hip_ctx_launch_order",
 ]
 
 
@@ -99,6 +100,10 @@ lib.snappy_hip_compress_shards.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ct
                                            ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, _vp,
                                            ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
                                            ctypes.POINTER(ctypes.c_uint64)]
+lib.snappy_hip_compress_shards_staged.argtypes = [ctypes.POINTER(_vp), ctypes.c_int, ctypes.POINTER(_vp),
+                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64, ctypes.c_int,
+                                                  _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                                  ctypes.POINTER(ctypes.c_uint64)]
 lib.snappy_hip_uncompress_d.argtypes = [_vp, _vp, ctypes.c_uint64, _vp, ctypes.c_uint64,
                                         ctypes.POINTER(ctypes.c_uint64), _vp]
 lib.snappy_hip_release_pool.restype = None
@@ -274,10 +279,12 @@ def _after_torch(stream, *tensors):
             return
 
 
-def compress_shards(ctxs, d_ins, lens, out_ptr, cap, framed=True):
-    """snappy_hip_compress_shards: shard k (device tensor d_ins[k], lens[k] bytes, on ctxs[k]'s GPU) is
-    encoded there, and all shards land in ONE host buffer (out_ptr: address, ideally page-locked) at
-    their scanned offsets.  Returns (written, offsets[n + 1])."""
+def compress_shards(ctxs, d_ins, lens, out_ptr, cap, framed=True, stage_blocks=0):
+    """snappy_hip_compress_shards(_staged): shard k (device tensor d_ins[k], lens[k] bytes, on ctxs[k]'s GPU)
+    is encoded there, and all shards land in ONE host buffer (out_ptr: address, ideally page-locked) at
+    their scanned offsets.  stage_blocks = S > 0: d_ins[k] holds context k's STAGES back to back -- stage j of
+    context k is the global block range [(j n + k) S, (j n + k + 1) S) -- and a context downloads a stage while
+    it encodes the next.  Returns (written, offsets[n + 1])."""
     n = len(ctxs)
     for c, t in zip(ctxs, d_ins):
         _after_torch(None, t)
@@ -286,8 +293,8 @@ def compress_shards(ctxs, d_ins, lens, out_ptr, cap, framed=True):
     ls = (ctypes.c_uint64 * n)(*[int(x) for x in lens])
     offs = (ctypes.c_uint64 * (n + 1))()
     w = ctypes.c_uint64()
-    st = _check_device(lib.snappy_hip_compress_shards(hs, n, ps, ls, int(framed), out_ptr, cap,
-                                                      ctypes.byref(w), offs))
+    st = _check_device(lib.snappy_hip_compress_shards_staged(hs, n, ps, ls, int(stage_blocks), int(framed),
+                                                             out_ptr, cap, ctypes.byref(w), offs))
     if st != OK:
         raise ValueError("compress_shards: status %d" % st)
     return w.value, list(offs)

@@ -968,18 +968,41 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
 // own GPU's link.  framed != 0: compressFramed (stream identifier + one chunk per block, any total
 // length); framed == 0: compress (one varint, total < 2^32).  out should be page-locked for the
 // downloads to overlap.  shard_off (may be NULL) receives the n + 1 scanned offsets.
-extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
-                                          const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
-                                          uint64_t* written, uint64_t* shard_off) {
+// Block ranges on n contexts, host-side concatenate (snappy.nim:56-62, :146-153), in STAGES so that a GPU encodes
+// while its earlier output travels: input k holds, back to back, the blocks of context k's stages; stage j of context
+// k is the global block range [(j n + k) S, (j n + k + 1) S) (S = stage_blocks; the last stage may be short, its ranges
+// still in context order), so the stream is the stages in order, each the contexts in order.  A context's thread
+// encodes + packs its stage, publishes the stage's size, and downloads -- on a second stream, behind an event -- every
+// earlier stage of its own whose place in `out` has become known (the sum of everything in front of it: the one
+// exchange of this path, n integers per stage through host memory), then goes on with the next stage: nobody waits
+// for a neighbour before its last stage.  stage_blocks = 0: one stage, i.e. n contiguous shards.
+extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
+                                                 const uint64_t* in_len, uint64_t stage_blocks, int framed, uint8_t* out,
+                                                 uint64_t cap, uint64_t* written, uint64_t* shard_off) {
   *written = 0;
   if (n <= 0) return SNAPPY_HIP_INVALID_INPUT;
-  for (int k = 0; k < n; k++)  // a context serves one shard at a time (it owns the scratch buffers its calls use)
+  for (int k = 0; k < n; k++) {  // a context serves one shard at a time (it owns the scratch buffers its calls use)
+    if (!ctxs[k]) return SNAPPY_HIP_INVALID_INPUT;
     for (int j = 0; j < k; j++)
-      if (ctxs[j] == ctxs[k] || !ctxs[k]) return SNAPPY_HIP_INVALID_INPUT;
+      if (ctxs[j] == ctxs[k]) return SNAPPY_HIP_INVALID_INPUT;
+  }
   uint64_t total_in = 0;
+  for (int k = 0; k < n; k++) total_in += in_len[k];
+  const uint64_t S = stage_blocks ? stage_blocks : ((uint64_t)1 << 40);
+  const uint64_t total_blocks = (total_in + kMaxBlockLen - 1) / kMaxBlockLen;
+  const uint64_t per_stage = S * (uint64_t)n;  // blocks of a full stage
+  const uint64_t n_stages = stage_blocks ? (total_blocks + per_stage - 1) / per_stage : 1;
+  // what context k holds of stage j, in bytes, by the layout above -- and the caller's lengths must agree with it
+  auto stage_bytes = [&](uint64_t j, int k) -> uint64_t {
+    if (!stage_blocks) return in_len[k];
+    const uint64_t lo = (j * n + (uint64_t)k) * S * kMaxBlockLen, hi = lo + S * kMaxBlockLen;
+    return total_in <= lo ? 0 : (total_in < hi ? total_in - lo : hi - lo);
+  };
   for (int k = 0; k < n; k++) {
-    if (k + 1 < n && in_len[k] % kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // shards are whole blocks
-    total_in += in_len[k];
+    uint64_t sum = 0;
+    for (uint64_t j = 0; j < n_stages; j++) sum += stage_bytes(j, k);
+    if (sum != in_len[k]) return SNAPPY_HIP_INVALID_INPUT;
+    if (!stage_blocks && k + 1 < n && in_len[k] % kMaxBlockLen) return SNAPPY_HIP_INVALID_INPUT;  // shards are whole blocks
   }
   if (!framed && total_in > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;  // snappy.nim:41-42
   const uint64_t need = framed ? snappy_hip_max_compressed_len_framed((int64_t)total_in)
@@ -992,84 +1015,160 @@ extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, co
   } else {
     base = (uint64_t)varint_encode_u32((uint32_t)total_in, out);
   }
-  std::vector<uint64_t> totals(n, 0);
-  std::vector<void*> packed(n, nullptr);
+  // sizes[j * n + k]: bytes of stage j of context k in the stream (~0: not known yet); the stream order is this index
+  std::vector<uint64_t> sizes(n_stages * n, ~0ull);
+  std::mutex mu;
+  std::condition_variable cv;
+  bool failed = false;
   std::vector<int> status(n, SNAPPY_HIP_OK);
   std::vector<std::string> errs(n);
   const int unit = framed ? kUnitFrame : kUnitBody;
-  auto phase1 = [&](int k) {  // encode + pack on GPU k, report the shard's size
+  // offset of stream piece `idx` if everything in front of it is known, else ~0 (caller holds mu)
+  auto place_of = [&](uint64_t idx) -> uint64_t {
+    uint64_t at = base;
+    for (uint64_t i = 0; i < idx; i++) {
+      if (sizes[i] == ~0ull) return ~0ull;
+      at += sizes[i];
+    }
+    return at;
+  };
+  auto worker = [&](int k) {
     snappy_hip_ctx* c = ctxs[k];
     DeviceGuard guard(c->device);
-    const uint64_t nb = (in_len[k] + kMaxBlockLen - 1) / kMaxBlockLen;
-    if (nb == 0) return;
-    void *d_slots, *d_sizes, *d_out;
-    int st;
-    if ((st = ws_get(c, 17, nb * (size_t)kSlotStride, &d_slots)) || (st = ws_get(c, 18, nb * 4 + (nb + 1) * 8 + 64, &d_sizes)) ||
-        (st = ws_get(c, 4, nb * (size_t)(kMaxCompressedBlockLen + 16) + 64, &d_out))) {
+    auto fail = [&](int st) {
       status[k] = st;
       errs[k] = g_last_error;
-      return;
+      std::lock_guard<std::mutex> lk(mu);
+      failed = true;
+      for (uint64_t j = 0; j < n_stages; j++)
+        if (sizes[j * n + k] == ~0ull) sizes[j * n + k] = 0;  // (nobody waits for me)
+      cv.notify_all();
+    };
+    const uint64_t nb_all = (in_len[k] + kMaxBlockLen - 1) / kMaxBlockLen;
+    const uint64_t nb_stage = stage_blocks ? (S < nb_all ? S : nb_all) : nb_all;
+    void *d_slots = nullptr, *d_sizes = nullptr, *d_out = nullptr;
+    int st = 0;
+    if (nb_all) {
+      if ((st = ws_get(c, 17, nb_stage * (size_t)kSlotStride, &d_slots)) ||
+          (st = ws_get(c, 18, nb_stage * 4 + (nb_stage + 1) * 8 + 64, &d_sizes)) ||
+          (st = ws_get(c, 4, nb_all * (size_t)(kMaxCompressedBlockLen + 16) + 64, &d_out)))
+        return fail(st);
     }
-    void* d_offsets = (uint8_t*)d_sizes + ((nb * 4 + 15) & ~(size_t)15);
-    if ((st = snappy_hip_encode_blocks_d(c, d_in[k], in_len[k], kMaxBlockLen, unit, (uint8_t*)d_slots, kSlotStride,
-                                         (uint32_t*)d_sizes, nullptr)) ||
-        (st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, nb, 0, (uint8_t*)d_out,
-                                (uint64_t*)d_offsets, nullptr))) {
-      status[k] = st;
-      errs[k] = g_last_error;
-      return;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t packed_ev = nullptr;
+    if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&packed_ev, hipEventDisableTiming) != hipSuccess) {
+      if (copy_stream) (void)hipStreamDestroy(copy_stream);
+      return fail(SNAPPY_HIP_DEVICE_ERROR);
     }
-    uint64_t end = 0;
-    if (hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
-      status[k] = SNAPPY_HIP_DEVICE_ERROR;
-      return;
-    }
-    totals[k] = end;
-    packed[k] = d_out;
-  };
-  // (one thread per shard; a shard whose thread cannot be had runs on this one: nothing crosses the C boundary)
-  auto fan_out = [&](auto&& phase) {
-    std::vector<std::thread> th;
-    std::vector<int> inline_k;
-    for (int k = 1; k < n; k++) {
-      try {
-        th.emplace_back(phase, k);
-      } catch (...) {
-        inline_k.push_back(k);
+    void* d_offsets = d_sizes ? (uint8_t*)d_sizes + ((nb_stage * 4 + 15) & ~(size_t)15) : nullptr;
+    std::vector<uint64_t> at_dev(n_stages + 1, 0);  // where my stages lie in d_out
+    uint64_t in_at = 0, next_copy = 0;
+    // download every stage of mine, in order, whose place is known (block = wait for it)
+    auto copy_ready = [&](uint64_t upto_stage, bool block) -> bool {
+      while (next_copy < upto_stage) {
+        const uint64_t idx = next_copy * n + (uint64_t)k;
+        uint64_t at;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          at = place_of(idx);
+          while (at == ~0ull && block && !failed) {
+            cv.wait(lk);
+            at = place_of(idx);
+          }
+          if (failed) return false;
+        }
+        if (at == ~0ull) return true;  // later
+        const uint64_t len = at_dev[next_copy + 1] - at_dev[next_copy];
+        if (at + len > cap) {
+          g_last_error = "internal: packed stream exceeds the caller's bound";
+          return false;
+        }
+        if (len && hipMemcpyAsync(out + at, (uint8_t*)d_out + at_dev[next_copy], len, hipMemcpyDeviceToHost, copy_stream) !=
+                       hipSuccess)
+          return false;
+        next_copy++;
       }
+      return true;
+    };
+    bool ok = true;
+    for (uint64_t j = 0; j < n_stages && ok; j++) {
+      const uint64_t bytes = stage_bytes(j, k);
+      const uint64_t nb = (bytes + kMaxBlockLen - 1) / kMaxBlockLen;
+      uint64_t end = at_dev[j];
+      if (nb) {
+        if ((st = snappy_hip_encode_blocks_d(c, d_in[k] + in_at, bytes, kMaxBlockLen, unit, (uint8_t*)d_slots, kSlotStride,
+                                             (uint32_t*)d_sizes, nullptr)) ||
+            (st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, nb, at_dev[j],
+                                    (uint8_t*)d_out, (uint64_t*)d_offsets, nullptr))) {
+          (void)hipStreamDestroy(copy_stream);
+          (void)hipEventDestroy(packed_ev);
+          return fail(st);
+        }
+        if (hipMemcpyAsync(&end, (uint64_t*)d_offsets + nb, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipEventRecord(packed_ev, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipStreamWaitEvent(copy_stream, packed_ev, 0) != hipSuccess)
+          ok = false;
+      }
+      at_dev[j + 1] = end;
+      in_at += bytes;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        sizes[j * n + k] = end - at_dev[j];
+        cv.notify_all();
+      }
+      ok = ok && copy_ready(j + 1, false);  // (what can go already goes; the next stage's kernels run beside it)
     }
-    phase(0);
-    for (int k : inline_k) phase(k);
-    for (auto& t : th) t.join();
+    ok = ok && copy_ready(n_stages, true) && hipStreamSynchronize(copy_stream) == hipSuccess;
+    (void)hipStreamSynchronize(copy_stream);
+    (void)hipStreamDestroy(copy_stream);
+    (void)hipEventDestroy(packed_ev);
+    if (!ok) fail(SNAPPY_HIP_DEVICE_ERROR);
   };
-  fan_out(phase1);
+  // (one thread per context; a context whose thread cannot be had would deadlock the others' waits for its sizes, so
+  // such a failure is reported before anything runs)
+  {
+    std::vector<std::thread> th;
+    try {
+      for (int k = 1; k < n; k++) th.emplace_back(worker, k);
+    } catch (...) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        for (auto& v : sizes)
+          if (v == ~0ull) v = 0;
+        cv.notify_all();
+      }
+      for (auto& t : th) t.join();
+      g_last_error = "could not start a thread per context";
+      return SNAPPY_HIP_DEVICE_ERROR;
+    }
+    worker(0);
+    for (auto& t : th) t.join();
+  }
   for (int k = 0; k < n; k++)
     if (status[k]) {
       g_last_error = errs[k];
       return status[k];
     }
-  std::vector<uint64_t> off(n + 1, base);  // the exchange: n totals -> exclusive scan
-  for (int k = 0; k < n; k++) off[k + 1] = off[k] + totals[k];
-  if (off[n] > cap) {
-    g_last_error = "internal: packed stream exceeds the caller's bound";
-    return SNAPPY_HIP_DEVICE_ERROR;
+  uint64_t total = base;
+  for (uint64_t v : sizes) total += v;
+  if (shard_off) {  // where each context's FIRST stage lies, and the stream's end (contiguous shards: the n + 1 scanned offsets)
+    uint64_t at = base;
+    for (int k = 0; k < n; k++) {
+      shard_off[k] = at;
+      at += sizes[k];
+    }
+    shard_off[n] = total;
   }
-  auto phase2 = [&](int k) {  // every shard lands at its scanned offset
-    snappy_hip_ctx* c = ctxs[k];
-    if (!totals[k]) return;
-    DeviceGuard guard(c->device);
-    if (hipMemcpyAsync(out + off[k], packed[k], totals[k], hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
-      status[k] = SNAPPY_HIP_DEVICE_ERROR;
-  };
-  fan_out(phase2);
-  for (int k = 0; k < n; k++)
-    if (status[k]) return status[k];
-  if (shard_off)
-    for (int k = 0; k <= n; k++) shard_off[k] = off[k];
-  *written = off[n];
+  *written = total;
   return SNAPPY_HIP_OK;
+}
+
+extern "C" int snappy_hip_compress_shards(snappy_hip_ctx* const* ctxs, int n, const uint8_t* const* d_in,
+                                          const uint64_t* in_len, int framed, uint8_t* out, uint64_t cap,
+                                          uint64_t* written, uint64_t* shard_off) {
+  return snappy_hip_compress_shards_staged(ctxs, n, d_in, in_len, 0, framed, out, cap, written, shard_off);
 }
 
 // =============================================================================================

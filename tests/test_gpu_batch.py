@@ -625,6 +625,24 @@ def test_shards_from_one_process_land_in_one_host_buffer(hip, orc, torch_mod):
     # one context cannot serve two shards at once (it owns the scratch buffers its calls use)
     with pytest.raises(ValueError):
         hip.compress_shards([ctxs[0], ctxs[0]], d_ins, lens, out.data_ptr(), cap, framed=False)
+    # the same in stages (snappy_hip_compress_shards_staged): stage j of context k is the global block range
+    # [(2 j + k) S, (2 j + k + 1) S), a context's stages lie back to back in its input, and a context downloads a
+    # stage while it encodes the next -- byte-identical again, whole stages, a short last stage, a ragged tail
+    B = 65536
+    for S in (16, 40, 7):
+        parts = [bytearray(), bytearray()]
+        for i, at in enumerate(range(0, len(src), S * B)):
+            parts[i % 2] += src[at:at + S * B]
+        d_st = [_dev(torch, np.frombuffer(bytes(q), dtype=np.uint8)) for q in parts]
+        for framed, want in ((True, orc.encode_framed(src)), (False, orc.encode(src))):
+            cap = hip.max_compressed_len_framed(len(src)) if framed else hip.max_compressed_len(len(src))
+            out = torch.zeros(cap, dtype=torch.uint8, pin_memory=True)
+            written, offs = hip.compress_shards(ctxs, d_st, [len(q) for q in parts], out.data_ptr(), cap, framed=framed,
+                                                stage_blocks=S)
+            assert out[:written].numpy().tobytes() == want, (S, framed)
+            assert offs[-1] == written
+        with pytest.raises(ValueError):  # lengths that are not what the stage layout gives the contexts
+            hip.compress_shards(ctxs, d_ins, lens, out.data_ptr(), cap, framed=False, stage_blocks=S)
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shards_one_process.py"), "--gpus", "2", "--same-gpu",
                          "--total-gib", "0.25", "--check", "--reps", "1"], capture_output=True, text=True, timeout=600)
     assert rc.returncode == 0, rc.stderr[-2000:]
