@@ -612,13 +612,28 @@ def _sharded_result(hip, ctx, corpus, rank, world, dev, total_blocks, requested_
 
 
 def self_launch(args, argv):
-    """--gpus N without a launcher: start the N ranks as a CHILD (this process has not touched a GPU and never
-    does), relay rank 0's JSON line, exit with the child's code."""
+    """--gpus N without a launcher: start the N ranks as a CHILD (this process does not touch a GPU: the devices
+    are counted from the kernel driver's topology files, not through the runtime), relay rank 0's JSON line, exit
+    with the child's code."""
     import socket
     import subprocess
-    # (counting devices does not touch the GPU on this image: a clear refusal instead of N - M ranks dying in set_device)
-    have = torch.cuda.device_count()
-    if have < args.gpus and not os.environ.get("BENCH_SHARE_DEVICE"):
+
+    def gpus_in_sysfs():
+        """GPU nodes of /sys/class/kfd/kfd/topology (simd_count > 0; CPUs have 0); None if it cannot be read"""
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        try:
+            n = 0
+            for node in os.listdir(top):
+                with open(os.path.join(top, node, "properties")) as fh:
+                    props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            return n
+        except (OSError, ValueError):
+            return None
+
+    # (a clear refusal instead of N - M ranks dying in set_device; unknown count: the child's exit code speaks)
+    have = gpus_in_sysfs()
+    if have is not None and have < args.gpus and not os.environ.get("BENCH_SHARE_DEVICE"):
         sys.stderr.write("bench.py: --gpus %d, but this node shows %d GPU(s)\n" % (args.gpus, have))
         sys.exit(2)
     with socket.socket() as so:

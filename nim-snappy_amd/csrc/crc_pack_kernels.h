@@ -149,26 +149,34 @@ __global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t
                                                                   uint64_t n, uint64_t base,
                                                                   uint64_t* offsets) {
   constexpr uint32_t kPer = 8;
-  __shared__ uint32_t s_wave[2][kScanThreads / 64];
+  // (64-bit sums throughout: the sizes of pack and of the frame scans are below 2^17, but the kernel also scans the
+  // tile sums of untrusted raw streams and a caller's sizes -- a pass of 8 192 of those can exceed 2^32, and the
+  // total this kernel reports is compared with the stream's declared length)
+  __shared__ uint64_t s_wave[2][kScanThreads / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) offsets[0] = base;
   uint64_t carry = base;  // (every thread keeps it: the pass total is read by all)
   uint32_t par = 0;
   for (uint64_t c = 0; c < n; c += (uint64_t)kScanThreads * kPer, par ^= 1) {
     const uint64_t i0 = c + (uint64_t)t * kPer;
-    uint32_t v[kPer];
+    uint64_t v[kPer];
 #pragma unroll
     for (uint32_t k = 0; k < kPer; k++) v[k] = i0 + k < n ? sizes[i0 + k] : 0;
 #pragma unroll
-    for (uint32_t k = 1; k < kPer; k++) v[k] += v[k - 1];  // (a pass sums at most 8 192 sizes of < 2^17: no overflow)
-    uint32_t wtot;
-    const uint32_t before_t = wave_excl_scan(v[kPer - 1], lane, &wtot);
-    if (lane == 0) s_wave[par][wv] = wtot;
+    for (uint32_t k = 1; k < kPer; k++) v[k] += v[k - 1];
+    uint64_t incl = v[kPer - 1];  // inclusive prefix sum over the wave
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint64_t up = __shfl_up(incl, d, 64);
+      incl += lane >= d ? up : 0;
+    }
+    const uint64_t before_t = incl - v[kPer - 1];
+    if (lane == 63) s_wave[par][wv] = incl;
     __syncthreads();  // (two buffers: the next pass's store cannot overtake this pass's loads)
-    uint32_t before_w = 0, pass_total = 0;
+    uint64_t before_w = 0, pass_total = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kScanThreads / 64; k++) {
-      const uint32_t w = s_wave[par][k];
+      const uint64_t w = s_wave[par][k];
       before_w += k < wv ? w : 0;
       pass_total += w;
     }

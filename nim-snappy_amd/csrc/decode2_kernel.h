@@ -504,6 +504,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
   const uint32_t fe_q = lane * 4 + shift;     // ring position of my quad, counted from a trip's first byte
   const uint32_t fe_q1 = (lane & 3) >= 1 ? 0xffffffffu : 0u, fe_q2 = (lane & 3) >= 2 ? 0xffffffffu : 0u;
   bool passed_on = false;
+#ifdef D2_INJECT_GIVE_UP
+  uint32_t d2_inject = 0;
+#endif
   uint4 pre[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
   uint32_t pq[2] = {0xffffffffu, 0xffffffffu};  // ring data in flight (ring wave)
 
@@ -1058,8 +1061,13 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
 #ifndef D2_LOOSE_POLL
         // (the wait is written out: read, wait, compare -- five instructions a poll; the compiler's form of the
         // loop below took eighteen scalar instructions a poll, and the scalar unit is shared by the CU's waves)
-        for (uint32_t spin = 0; front < expect; spin += 1024) {
-          uint32_t left = 1024, fv;
+#ifdef D2_INJECT_GIVE_UP  // (tests/test_gpu_faults.py: every k-th turn that has to be waited for is given up on at once)
+        const uint32_t looks = (front < expect && (++d2_inject % (D2_INJECT_GIVE_UP)) == 0) ? 1 : 1024;
+#else
+        constexpr uint32_t looks = 1024;
+#endif
+        for (uint32_t spin = looks == 1024 ? 0 : 400001; front < expect; spin += 1024) {
+          uint32_t left = looks, fv;
           const uint32_t fa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_front;
           asm volatile(
               "1:\n"

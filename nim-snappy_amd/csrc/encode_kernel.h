@@ -29,6 +29,18 @@
 
 #include "common.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "encode_kernel.h relies on LDS atomics serving the lanes of one address in ascending lane order -- checked at run time, but verified (tools/probes/mskor_probe.hip, cmpst_probe.hip) on gfx950 only"
+#endif
+// -DENC_INJECT_ORDER_FAULT=<k> (tests/test_gpu_faults.py builds such a library; never the shipped one): every k-th
+// look at an order-of-service check finds it failed, so that the recovery code behind the checks -- which the
+// hardware never sends anybody into -- runs under the parity tests.
+#ifdef ENC_INJECT_ORDER_FAULT
+#define ENC_ORDER_FAULT() ((++enc_inject % (ENC_INJECT_ORDER_FAULT)) == 0)
+#else
+#define ENC_ORDER_FAULT() false
+#endif
+
 namespace snappy_hip {
 
 constexpr uint32_t kSeqLen = 320;  // probe-sequence entries (offset passes 65536 at ~250)
@@ -350,6 +362,8 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // DEBUG section timers
   uint32_t rounds = 0, c_fast = 0, c_bail_ms = 0, c_bail_order = 0, c_cont = 0, c_fresh_nohas = 0;  // DEBUG
+  uint32_t enc_inject = 0;  // (ENC_INJECT_ORDER_FAULT)
+  (void)enc_inject;
   auto tick = [&](int k) {
     if (SNAPPY_STATS(prm)) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
                      : "memory");
         wave_fence();
       };
-      if (__builtin_expect(ballot(inround && old - base >= lane) != 0, 0)) {  // not served in ascending order
+      if (__builtin_expect(ballot(inround && old - base >= lane) != 0 || ENC_ORDER_FAULT(), 0)) {  // not served in ascending order
         undo_table();
         c_bail_order++;
         break;
@@ -482,7 +496,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
                        : "memory");
           const uint64_t ON = ballot((ret == lane) & (lane != 63));  // the copy ends the chain went on from (lane 1 among them)
           const uint32_t f = readfirst(fin);
-          if (__builtin_expect(f >= 63, 1)) {
+          if (__builtin_expect(f >= 63 && !ENC_ORDER_FAULT(), 1)) {
             walked = true;
             const uint32_t last = 63 - (uint32_t)__builtin_clzll(ON);
             if (f == 255) {  // nothing found from the last of them: the round ends there
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       old = (ret >> sh16) & 0xffffu;
       const bool inround = old >= base;  // (nothing at or behind base has been inserted before this round)
       any_conflict = ballot(inround) != 0;
-      if (__builtin_expect(ballot(inround && old - base >= lane) != 0, 0)) {
+      if (__builtin_expect(ballot(inround && old - base >= lane) != 0 || ENC_ORDER_FAULT(), 0)) {
         wave_fence();
         s_table[inround ? tsink : h] = (uint16_t)old;  // the first-served lane of every slot puts back what it saw
         wave_fence();

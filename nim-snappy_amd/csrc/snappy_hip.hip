@@ -1395,7 +1395,7 @@ class CopyPool {  // parallel memcpy; the threads live as long as the process (n
   int n_threads_ = 0;
 };
 
-// SNAPPY_HIP_PIN_HOST = 3 (default): the staging ring.  (0: the runtime's pageable copies; 1, 2: page-lock the
+// SNAPPY_HIP_PIN_HOST = 3 (NOT the default, which is 0): the staging ring.  (0: the runtime's pageable copies; 1, 2: page-lock the
 // caller's buffers, see HostPin.)
 inline bool stage_ready(snappy_hip_ctx* c, bool small_side) {
   // 3: every bulk copy through the ring; 4: only the smaller direction of a call (the compressed side), the

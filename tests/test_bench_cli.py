@@ -31,10 +31,19 @@ def test_self_launch_relays_the_childs_exit_code():
     if torch.cuda.is_available():
         import pytest
         pytest.skip("a GPU is present: the self-launch path is covered by the -m gpu bench test")
+    # (BENCH_SHARE_DEVICE skips the parent's device count, so that the child is really started -- and fails)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--blocks", "16", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=600, env=_env())
+                       capture_output=True, text=True, timeout=600, env=_env(BENCH_SHARE_DEVICE="1"))
     assert r.returncode != 0
+    assert "torch.distributed" in r.stderr or "Traceback" in r.stderr or "rank" in r.stderr.lower(), r.stderr[-800:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # without the hook the parent refuses a node that shows fewer GPUs than asked for (exit code 2, one line) -- when
+    # it can count them: on a box without the driver's topology files the child's exit code speaks instead
+    r2 = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--blocks", "16", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True, timeout=600, env=_env())
+    assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    if os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        assert r2.returncode == 2 and "GPU(s)" in r2.stderr
 
 
 def test_threaded_oracle_helpers_equal_the_serial_ones(orc):
