@@ -54,21 +54,30 @@ BLOCK = 65536
 
 
 def measured_traffic(nb, only, kernels=("decode_indexed_kernel<32768>", "decode_indexed_kernel")):
-    """HBM bytes per launch of a kernel from the PMC passes of tools/profile_bench.sh
-    (FETCH_SIZE / WRITE_SIZE cannot be read inside this process: they need their own rocprofv3
-    passes).  The committed measurement is for the default workload only; anything else: None."""
+    """(HBM bytes per launch of a kernel, note) from the PMC passes of tools/profile_bench.sh (FETCH_SIZE / WRITE_SIZE
+    cannot be read inside this process: they need their own rocprofv3 passes).  The committed measurement is for
+    the default workload only, and for ONE state of the kernel sources: the file carries their sha256
+    (tools/build_id.py), and a profile of other sources is not reported -- (None, why) instead."""
     if nb != 65536 or only is not None:
-        return None
+        return None, "the committed profile is of the default workload (65536 blocks, class mix)"
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
     if not cands:
-        return None
-    with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
-        t = json.load(f)
-    for name in kernels:
-        k = t.get("kernels", {}).get(name)
-        if k is not None:
-            return k["total_bytes"]
-    return None
+        return None, "no profiles/*_traffic.json"
+    import build_id
+    mine = build_id.csrc_sha256(ROOT)
+    stale = None
+    for name in reversed(cands):  # the newest profile of THESE sources
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            t = json.load(f)
+        if t.get("csrc_sha256") != mine:
+            stale = stale or name
+            continue
+        for k in kernels:
+            v = t.get("kernels", {}).get(k)
+            if v is not None:
+                return v["total_bytes"], "profiles/%s (csrc_sha256 %s)" % (name, mine[:16])
+    return None, ("no profile of these kernel sources (csrc_sha256 %s); the newest, profiles/%s, is of %s: run "
+                  "tools/profile_bench.sh" % (mine[:16], stale, "other sources" if stale else "nothing"))
 
 
 def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_all):
@@ -186,6 +195,88 @@ def config1_alice29(hip):
                                 round(mean_ms(lambda: hip.decode_framed(fr)), 4)],
         "reference_README_x86_64": {"raw": [0.334, 0.186], "framed": [0.382, 0.251]},
     }
+
+
+README_TABLE = {  # /root/reference/README.md:99-124, inMemory column: ms per call, encode / decode (x86_64, one thread)
+    "html": ((0.086, 0.056), (0.117, 0.093)), "urls.10K": ((1.052, 0.480), (1.260, 0.775)),
+    "fireworks.jpeg": ((0.008, 0.005), (0.051, 0.047)), "paper-100k.pdf": ((0.010, 0.006), (0.046, 0.050)),
+    "html_x_4": ((0.374, 0.218), (0.491, 0.386)), "alice29.txt": ((0.334, 0.186), (0.382, 0.251)),
+    "asyoulik.txt": ((0.300, 0.165), (0.343, 0.220)), "lcet10.txt": ((0.907, 0.483), (1.053, 0.675)),
+    "plrabn12.txt": ((1.241, 0.646), (1.387, 0.856)), "geo.protodata": ((0.076, 0.050), (0.110, 0.095)),
+    "kppkn.gtb": ((0.279, 0.183), (0.346, 0.261)), "Mark.Twain-Tom.Sawyer.txt": ((0.024, 0.018), (0.030, 0.021)),
+}
+README_STATE = {"bytes": 38942424, "raw": (23.814, 8.608), "framed": (36.075, 25.389)}  # README.md:123-124 (50 calls)
+
+
+def config_readme_files(hip, corpus, ctx, dev, calls=30):
+    """The reference's own benchmark table (README.md:97-125, tests/benchmark.nim:93-126,178-180) on this box: every
+    data file of the table, raw and framed, ms per call encode / decode, mean over `calls` calls the way
+    benchmark.nim's timeit does -- the oracle on one host core (the Nim inMemory column cannot be built here)
+    beside the HIP library's host-buffer calls (PCIe and launch latency included).  The table's last row is a
+    38 942 424-byte beacon state that is not in the reference's tree: a synthetic buffer of that size (the bench's
+    corpus mix), through the host calls and through the device-resident calls (p50 of 20)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+
+    def mean_ms(f, reps):
+        f()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f()
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
+
+    def p50_ms(f, reps=20):
+        f()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return round(sorted(ts)[len(ts) // 2] * 1e3, 4)
+
+    rows = []
+    for name, (ref_raw, ref_fr) in README_TABLE.items():
+        with open(os.path.join(ROOT, "tests", "golden", "data", name), "rb") as fh:
+            src = fh.read()
+        enc, fr = orc.encode(src), orc.encode_framed(src)
+        assert hip.encode(src) == enc and hip.encode_framed(src) == fr and hip.decode(enc) == src and hip.decode_framed(fr) == src
+        rows.append({
+            "file": name, "bytes": len(src),
+            "oracle_raw": [mean_ms(lambda: orc.encode(src), calls), mean_ms(lambda: orc.decode(enc), calls)],
+            "hip_host_raw": [mean_ms(lambda: hip.encode(src), calls), mean_ms(lambda: hip.decode(enc), calls)],
+            "oracle_framed": [mean_ms(lambda: orc.encode_framed(src), calls), mean_ms(lambda: orc.decode_framed(fr), calls)],
+            "hip_host_framed": [mean_ms(lambda: hip.encode_framed(src), calls), mean_ms(lambda: hip.decode_framed(fr), calls)],
+            "reference_README_inMemory": {"raw": list(ref_raw), "framed": list(ref_fr)},
+        })
+    # the 38.9 MB single buffer
+    n = README_STATE["bytes"]
+    nb = -(-n // BLOCK)
+    d_src = corpus.make_blocks_torch(torch, 0, nb, dev).reshape(-1)[:n].contiguous()
+    src = d_src.cpu().numpy().tobytes()
+    enc, fr = hip.encode(src), hip.encode_framed(src)
+    assert hip.decode(enc) == src and hip.decode_framed(fr) == src
+    d_fr = torch.empty(hip.max_compressed_len_framed(n), dtype=torch.uint8, device=dev)
+    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
+    flen = ctx.compress_framed(d_src, n, d_fr, d_fr.numel())
+    assert flen == len(fr) and ctx.uncompress_framed(d_fr, flen, d_back, n) == (0, flen, n) and bool(torch.equal(d_back, d_src))
+    d_raw = torch.frombuffer(bytearray(enc), dtype=torch.uint8).to(dev)
+    assert ctx.uncompress(d_raw, len(enc), d_back, n) == (0, n) and bool(torch.equal(d_back, d_src))
+    state = {
+        "bytes": n, "data": "synthetic (corpus mix; the reference's state file is not in its tree)",
+        "compressed_bytes": {"raw": len(enc), "framed": len(fr)},
+        "oracle_raw": [mean_ms(lambda: orc.encode(src), 3), mean_ms(lambda: orc.decode(enc), 3)],
+        "oracle_framed": [mean_ms(lambda: orc.encode_framed(src), 3), mean_ms(lambda: orc.decode_framed(fr), 3)],
+        "hip_host_raw_p50": [p50_ms(lambda: hip.encode(src)), p50_ms(lambda: hip.decode(enc))],
+        "hip_host_framed_p50": [p50_ms(lambda: hip.encode_framed(src)), p50_ms(lambda: hip.decode_framed(fr))],
+        # input and output resident in HBM (snappy_hip_compress_framed_d / _uncompress_framed_d / _uncompress_d)
+        "hip_device_framed_p50": [p50_ms(lambda: ctx.compress_framed(d_src, n, d_fr, d_fr.numel())),
+                                  p50_ms(lambda: ctx.uncompress_framed(d_fr, flen, d_back, n))],
+        "hip_device_raw_decode_p50": p50_ms(lambda: ctx.uncompress(d_raw, len(enc), d_back, n)),
+        "reference_README_inMemory": {"raw": list(README_STATE["raw"]), "framed": list(README_STATE["framed"]),
+                                      "note": "another buffer (a real beacon state), x86_64, one thread, 50 calls"},
+    }
+    return {"what": "README.md:97-125 / tests/benchmark.nim on this box: ms per call, [encode, decode]", "calls": calls,
+            "files": rows, "state_38_9MB": state}
 
 
 def host_api_rates(hip, src_np, ctx=None, dev=None):
@@ -871,7 +962,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "measured_copy_GBps": round(copy_gbps, 1),  # device-to-device copy, read + write
                 "frac_of_measured_copy": round(achieved / copy_gbps, 5),
-                "traffic": measured_traffic(nb, args.only),
+                "traffic": measured_traffic(nb, args.only)[0],
+                "traffic_source": measured_traffic(nb, args.only)[1],  # (null traffic: why)
                 "kernel": "decode_indexed_kernel<32768>",  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),  # (HIP events; rocprof's average for this kernel agrees)
                 "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
@@ -892,7 +984,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round((u_bytes + sum_c) / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if enc_ms else 0.0,
-                "traffic": measured_traffic(nb, args.only, ("encode_blocks_kernel",)),
+                "traffic": measured_traffic(nb, args.only, ("encode_blocks_kernel",))[0],
                 "kernel": "encode_blocks_kernel",
                 "kernel_ms": round(enc_ms, 4),
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
@@ -915,6 +1007,7 @@ def main():
                 "compress": round(line["compress_GBps"] / cb["compress_threads_value"], 2),
                 "decompress": round(line["value"] / cb["threads_value"], 2), "host_cpus": cb["host_cpus"]}
             line["config1_alice29"] = config1_alice29(hip)
+            line["config_readme_files"] = config_readme_files(hip, corpus, ctx, dev)
             del d_packed, d_out
             line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 8192))
             line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy(), ctx, dev)

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnappy_hip.so")
 SOURCES = ["snappy_hip.hip", "common.h", "decode_kernel.h", "decode2_kernel.h", "index_kernel.h",
-           "encode_kernel.h", "crc_pack_kernels.h", "framed_kernels.h", "split_kernels.h"]
+           "encode_kernel.h", "crc_pack_kernels.h", "framed_kernels.h", "split_kernels.h", "sparse_kernel.h"]
 
 
 def _stale():

@@ -85,6 +85,11 @@ struct IndexParams {
   int unit;
   uint32_t* blk_in;  // split mode: stream position (after the varint) where output block k starts
   const uint32_t* order;  // workgroup i takes unit order[i] (nullptr: unit i)
+  // Units of 2 .. sparse_max elements whose stream is longer than the indexed decoder's stream ring get the status
+  // kNeedsSparse: few, long elements (long literals, stretches of 64-byte copies) are the business of sparse_kernel.h.
+  // (One element: a literal, copied straight by the indexed decoder; a short stream of many copies: a period, written
+  // from one image there.)  0: never.
+  uint32_t sparse_max;
 };
 
 // Decode "the element that would start here" from its tag and the four bytes after it.
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     }
   };
   bool strad_before = false;  // SPLIT: a straddling element in an earlier chunk
+  uint32_t n_elem_lane = 0;   // elements that start in my regions, over all chunks (sparse verdict)
   unsigned long long tA = 0, tW = 0, tC = 0, tt0 = 0, tt1 = 0, tt2 = 0;  // DEBUG (SPLIT, prm.idx != nullptr)
   const bool dbgt = SPLIT && prm.idx != nullptr;
   if (SPLIT && wave == 0) post(0, 0, 0, 0, false);
@@ -511,6 +517,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
       idx[2 * (rs / kRegion) + 1] = (bm >> kSub) ? (bm >> kSub) | (pos1 << 16) : idx_none(pos0 + out_here);
     }
     }
+    n_elem_lane += nelem_here;
     op += tot;
     if (SPLIT) {
       const bool strad = strad_before || ballot(straddle) != 0;
@@ -543,6 +550,11 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
+  if (prm.sparse_max && n > 4096) {
+    uint32_t n_elem;
+    (void)wave_excl_scan(n_elem_lane, lane, &n_elem);
+    if (n_elem >= 2 && n_elem <= prm.sparse_max) return finish(kNeedsSparse, op);
+  }
   finish(kOk, op);
 }
 

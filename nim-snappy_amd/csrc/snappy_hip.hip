@@ -26,6 +26,7 @@
 #include "encode_kernel.h"
 #include "framed_kernels.h"
 #include "index_kernel.h"
+#include "sparse_kernel.h"
 #include "split_kernels.h"
 
 using namespace snappy_hip;
@@ -111,7 +112,7 @@ struct DeviceGuard {
 
 }  // namespace
 
-constexpr int kTimeSlots = 10;  // snappy_hip_ctx_kernel_ms(which)
+constexpr int kTimeSlots = 11;  // snappy_hip_ctx_kernel_ms(which)
 struct snappy_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -598,6 +599,9 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       HIP_TRY(hipMemsetAsync(d_stats, 0, 256, s));
       dp.stats = d_stats;
     }
+    // (units of few, long elements go to the element-parallel kernel, sparse_kernel.h: the index pass names them)
+    const bool sparse_on = kD2RingFirst && !dbg_env("SNAPPY_HIP_NO_RING") && !dbg_env("SNAPPY_HIP_NO_SPARSE");
+    ip.sparse_max = sparse_on ? kSparseMax : 0;
     {
       LaunchTimer lt(c, s, 4);
       LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
@@ -630,6 +634,28 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
         LAUNCH((decode_indexed_kernel<kRingWin, true>), dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
       else
         LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
+    }
+    if (sparse_on) {  // the sparse units, as a list; the kernel's workgroups take them in turn (what it cannot do: kNeedsWindow)
+      void* d_sp;
+      if ((st = ws_get(c, 21, 8 + n_units * 4, &d_sp))) return st;
+      HIP_TRY(hipMemsetAsync(d_sp, 0, 8, s));
+      LAUNCH(status_list_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_status,
+             dp.order, n_units, kNeedsSparse, (uint32_t*)d_sp + 2);
+      SparseParams sp{};
+      sp.in = d_in;
+      sp.in_off = d_in_off;
+      sp.in_len = d_in_len;
+      sp.out = d_out;
+      sp.out_off = d_out_off;
+      sp.out_len = d_out_len;
+      sp.status = d_status;
+      sp.idx_off = (const uint64_t*)d_ioff;
+      sp.idx_stride = stride;
+      sp.idx = (const uint32_t*)d_idx;
+      sp.unit = unit;
+      sp.list = (const uint32_t*)d_sp + 2;
+      LaunchTimer lt(c, s, 10);
+      LAUNCH(decode_sparse_kernel, dim3((uint32_t)(n_units < 8192 ? n_units : 8192)), dim3(kSparseThreads), 0, s, sp);
     }
     if (ring_first) {  // the units it passed on, as a list
       void* d_pass;

@@ -65,3 +65,37 @@ def test_threaded_oracle_helpers_equal_the_serial_ones(orc):
     orc.lib.sor_encode_frames_mt(b.ctypes.data, b.size, 65536, o.ctypes.data, slot, s.ctypes.data, 3)
     fr = b"".join(o[i * slot:i * slot + s[i]].tobytes() for i in range(nb))
     assert bytes([0xff, 6, 0, 0, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59]) + fr == orc.encode_framed(b.tobytes())
+
+
+def test_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py reports a committed PMC traffic figure only for the kernel sources it was measured on
+    (profiles/*_traffic.json carries their sha256, tools/build_id.py): otherwise null and the reason"""
+    import importlib.util
+    import json
+    import build_id
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    (root / "nim-snappy_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "nim-snappy_amd" / "csrc" / "k.h").write_text("// kernel v1\n")
+    (root / "include" / "snappy_hip.h").write_text("// abi\n")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    sha1 = build_id.csrc_sha256(str(root))
+    kern = {"kernels": {"decode_indexed_kernel<32768>": {"total_bytes": 7.0e9}}}
+    (root / "profiles" / "r01_traffic.json").write_text(json.dumps(dict(kern, csrc_sha256=sha1)))
+    v, why = bench.measured_traffic(65536, None)
+    assert v == 7.0e9 and "r01_traffic.json" in why
+    # another workload: never
+    assert bench.measured_traffic(1024, None)[0] is None and bench.measured_traffic(65536, "T_TEXT")[0] is None
+    # the sources change: the profile is stale, nothing is reported, and the reason says so
+    (root / "nim-snappy_amd" / "csrc" / "k.h").write_text("// kernel v2\n")
+    v, why = bench.measured_traffic(65536, None)
+    assert v is None and "r01_traffic.json" in why and "other sources" in why
+    # a profile without a hash (older rounds) is not trusted either; a newer one of these sources is
+    (root / "profiles" / "r00_traffic.json").write_text(json.dumps(kern))
+    assert bench.measured_traffic(65536, None)[0] is None
+    (root / "profiles" / "r02_traffic.json").write_text(json.dumps(dict(kern, csrc_sha256=build_id.csrc_sha256(str(root)))))
+    assert bench.measured_traffic(65536, None)[0] == 7.0e9

@@ -1,5 +1,7 @@
 """Condense the rocprofv3 outputs of tools/profile_bench.sh into one markdown summary."""
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_id
 out = sys.argv[1]
 def short(k):
     # the indexed decoder's two instantiations: ring window first, whole-block window for what it passes on
@@ -57,7 +59,8 @@ kern = {k: {"read_bytes": 2.0 * v.get("FETCH_SIZE", 0.0), "write_bytes": v.get("
             "total_bytes": 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)}
         for k, v in tr.items() if "kernel" in k and not k.startswith("void")}
 with open(os.path.join(out, "traffic.json"), "w") as fh:
-    json.dump({"workload": "bench.py --steps 2 --warmup 1 --no-cpu (65536 x 64 KiB blocks, class mix default, seed 0x5EED5AA9), 1 x MI355X",
+    json.dump({"csrc_sha256": build_id.csrc_sha256(),  # the kernel sources this was measured on (bench.py checks it)
+               "workload": "bench.py --steps 2 --warmup 1 --no-cpu (65536 x 64 KiB blocks, class mix default, seed 0x5EED5AA9), 1 x MI355X",
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = KB x 1024, "
                          "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section); mean per dispatch.  FETCH_SIZE counts "
                          "the L2's requests to the fabric, Infinity Cache hits included",
