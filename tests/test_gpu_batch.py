@@ -791,3 +791,138 @@ def test_pool_release_and_caller_stream(hip, orc, torch_mod):
     assert launches > 0, "the caller's stream took the serial whole-stream kernel"
     assert d_out.cpu().numpy().tobytes() == src
     ctx.close()
+
+
+def _sparse_stream(rng, style, target=65536):
+    """One block's tag stream of FEW, LONG elements (sparse_kernel.h): long literals with stretches of copies behind
+    them -- the repeated-strings pattern -- plus everything that kernel treats specially: literals of every length
+    class (1..60, length bytes, above and below its whole-wave threshold), copy1 / copy2 / copy4, copies that overlap
+    themselves (offset < length), copies whose source spans several elements, chains of copies through copies
+    (levels), more long literals than its list holds, and -- style 'deep' -- more levels than it goes."""
+    out, body = bytearray(), bytearray()
+
+    def lit(n):
+        data = rng.randbytes(n)
+        m = n - 1
+        if m < 60:
+            body.append(m << 2)
+        else:
+            ll = max((m.bit_length() + 7) // 8, 1)
+            body.extend(bytes([(59 + ll) << 2]) + m.to_bytes(ll, "little"))
+        body.extend(data)
+        out.extend(data)
+
+    def copy(off, ln, form=None):
+        form = form or (1 if 4 <= ln <= 11 and off < 2048 and rng.random() < 0.5 else 2)
+        if form == 1:
+            body.extend(bytes([((off >> 8) << 5) | ((ln - 4) << 2) | 1, off & 0xff]))
+        elif form == 2:
+            body.extend(bytes([((ln - 1) << 2) | 2]) + off.to_bytes(2, "little"))
+        else:
+            body.extend(bytes([((ln - 1) << 2) | 3]) + off.to_bytes(4, "little"))
+        for _ in range(ln):
+            out.append(out[-off])
+
+    def run(off, total):
+        while total > 0 and len(out) < target:
+            ln = min(total, 64, target - len(out))
+            copy(off, ln, 2)
+            total -= ln
+
+    while len(out) < target:
+        room = target - len(out)
+        r = rng.random()
+        if style == "deep" and len(out) > 3000:  # every copy reads the copy in front of it: as many levels as copies
+            copy(64, min(room, 64), 2)
+            continue
+        if style == "manylits" and len(out) < 40000:
+            lit(min(room, rng.randint(256, 300)))  # ~140 literals above the whole-wave threshold (its list holds 64)
+            continue
+        if r < 0.5 or not out:
+            n = min(room, rng.choice([1, 17, 60, 61, 200, 255, 256, 257, 1000, 4000, 9000]))
+            lit(n)
+            if len(out) < target and rng.random() < 0.8:  # ... repeated behind itself, one to three times
+                run(min(n, len(out)), min(target - len(out), n * rng.randint(1, 3)))
+        elif r < 0.6:
+            copy(rng.randint(1, min(len(out), 63)), min(room, rng.randint(2, 64)), 2)          # overlaps itself (or not)
+        elif r < 0.7:
+            copy(rng.randint(1, min(len(out), 65535)), min(room, rng.randint(1, 64)), 3)       # copy4
+        elif r < 0.8:
+            copy(rng.randint(1, min(len(out), 2047)), min(room, rng.randint(4, 11)), 1)        # copy1
+        else:
+            off = rng.randint(1, min(len(out), 65535))
+            run(off, min(room, rng.randint(64, 3000)))                                         # a stretch at any distance
+    return bytes(body), bytes(out)
+
+
+def test_sparse_units_decoder(hip, orc, torch_mod):
+    """units of few, long elements take the element-parallel kernel (sparse_kernel.h: the index pass names units of 2
+    to 1 024 elements whose stream is longer than 4 KiB): the repeated-strings pattern and every element form that
+    kernel treats specially, outputs at unaligned addresses, with and without the CRC; what it does not do (more
+    levels than it goes) comes out right through the indexed decoder; a bad offset is refused like the oracle refuses it"""
+    torch = torch_mod
+    rng = random.Random(4242)
+    units = []
+    for i in range(96):
+        style = ("rs", "rs", "manylits", "deep", "rs", "rs")[i % 6]
+        target = 65536 if i % 4 else rng.randint(9000, 65536)
+        units.append(_sparse_stream(rng, style, target))
+    # bad offsets: a copy that reaches in front of the output (decoder.nim:112), at the start and in the middle
+    bad_units = []
+    for k in range(6):
+        b, p = units[k]
+        bb = bytearray(b)
+        if k % 2 == 0:
+            bb = bytearray(bytes([(63 << 2) | 2, 0xff, 0xff])) + bb  # copy2 of 64 bytes at output position 0
+        else:
+            bb += bytes([(3 << 2) | 2, 0, 0])  # offset 0
+        bad_units.append(bytes(bb))
+    n_el = []
+    for b, p in units:
+        assert orc.decode_all_tags(b, len(p)) == (0, p)
+    all_units = [(b, p, True) for b, p in units] + [(b, b"", False) for b in bad_units]
+    nu = len(all_units)
+    in_off, out_off, pos, opos = [], [], 0, 0
+    for k, (b, p, ok) in enumerate(all_units):
+        in_off.append(pos)
+        pos += len(b) + rng.randint(0, 7)
+        opos += 0 if k % 3 == 0 else rng.randint(1, 15)
+        if k % 3 == 0:
+            opos = (opos + 15) & ~15
+        out_off.append(opos)
+        opos += 65536
+    stream = np.zeros(pos + 64, np.uint8)
+    for j, o in enumerate(in_off):
+        stream[o:o + len(all_units[j][0])] = np.frombuffer(all_units[j][0], np.uint8)
+    ctx = hip.Context(0)
+    d_stream = _dev(torch, stream)
+    d_in_off = _dev(torch, np.array(in_off, np.int64))
+    d_in_len = _dev(torch, np.array([len(u[0]) for u in all_units], np.int32))
+    d_out_off = _dev(torch, np.array(out_off, np.int64))
+    d_out_cap = _dev(torch, np.array([65536] * nu, np.int32))
+    for with_crc in (False, True):
+        d_out_len = torch.zeros(nu, dtype=torch.int32, device="cuda")
+        d_status = torch.full((nu,), 77, dtype=torch.int32, device="cuda")
+        d_dec = torch.zeros(opos, dtype=torch.uint8, device="cuda")
+        d_crc = torch.zeros(nu, dtype=torch.int32, device="cuda") if with_crc else None
+        ctx.timing(True)
+        ctx.decode_blocks(d_stream, d_in_off, d_in_len, nu, d_dec, d_out_off, d_out_cap, d_out_len, d_status,
+                          unit=hip.UNIT_BODY, d_crc=d_crc)
+        ctx.sync()
+        sparse_launches = ctx.kernel_ms(10)[1]
+        ctx.timing(False)
+        assert sparse_launches >= 1
+        st = d_status.cpu().numpy()
+        ol = d_out_len.cpu().numpy()
+        got = d_dec.cpu().numpy()
+        for j, (b, p, ok) in enumerate(all_units):
+            want_st, want_out = orc.decode_all_tags(b, 65536)
+            assert int(st[j]) == want_st, (j, int(st[j]), want_st)
+            if ok:
+                assert want_st == 0 and int(ol[j]) == len(p)
+                assert got[out_off[j]:out_off[j] + len(p)].tobytes() == p, (with_crc, j)
+                if with_crc:
+                    assert int(d_crc[j].item()) & 0xffffffff == orc.masked_crc(p), j
+            else:
+                assert want_st == hip.INVALID_INPUT and int(ol[j]) == 0
+    ctx.close()
