@@ -82,7 +82,7 @@ struct Decode2Params {
   uint32_t* timeouts;  // [1] turns that were given up on (see the resolvers' wait): never, on a consistent index
   int second;  // the launch after the ring-window one: only the units that one passed on (kNeedsWindow)
   const uint32_t* pass_list;  // ... listed by passed_on_list_kernel; pass_list[-2] = how many
-  int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no walk, 8 no flush
+  int dbg;  // timing experiments: 1 no literal payloads, 2 no resolver, 4 no front end, 8 no flush, 16 no read-backs from HBM
   unsigned long long* stats;  // DEBUG counters (nullptr = off)
   // masked CRC32C of every unit's output, computed from the LDS window while it is flushed
   // (nullptr = not wanted); crc_done[u] = 1 where it was written (the units this kernel declines
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
           bool anyfar = false;
 #pragma unroll
           for (uint32_t j = 0; j < B; j++) {
-            fj[j] = cp[j] && sp[j] < ring_lo;
+            fj[j] = cp[j] && sp[j] < ring_lo && !(SNAPPY_DBG(prm) & 16);  // (DEBUG 16: no read-backs -- wrong bytes, timing only)
             anyfar = anyfar || fj[j];
           }
           if (__builtin_expect(ballot(anyfar) != 0, 0)) {

@@ -13,7 +13,8 @@ def short(k):
     for name in ("decode_indexed_kernel", "index_units_kernel", "decode_units_kernel", "encode_blocks_kernel",
                  "crc32c_units_kernel", "gather_slots_kernel", "scan_sizes_kernel", "region_counts_kernel",
                  "frame_chase_kernel", "frame_stitch_kernel", "frame_fill_kernel", "frame_scatter_kernel",
-                 "frame_scan_kernel", "frame_verdict_kernel", "copy_units_kernel", "split_walk_kernel",
+                 "frame_scan_kernel", "frame_verdict_kernel", "copy_units_kernel", "split_walk_kernel", "decode_sparse_kernel",
+                 "status_list_kernel", "passed_on_list_kernel",
                  "split_check_kernel", "encode_sketch_kernel", "order_count_kernel", "order_scan_kernel",
                  "order_scatter_kernel"):
         if name in k:
@@ -34,16 +35,36 @@ for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     for row in csv.DictReader(open(f)):
         print("| %s | %s | %.3f | %.4f | %s |" % (short(row["Name"]), row["Calls"], float(row["TotalDurationNs"]) / 1e6,
                                                  float(row["AverageNs"]) / 1e6, row["Percentage"]))
-print("\n## HBM traffic per launch (separate --pmc passes; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)\n")
+# the library's kernels by grid size: the bench launches some of them on batches of several sizes (the staged sharded
+# compress encodes 16 384 blocks a launch, the headline legs 65 536), and an average over all of them says nothing
+print("\n## the library's kernels by launch size (same pass: kernel_trace.csv)\n")
+ours = ("decode_indexed_kernel", "index_units_kernel", "decode_units_kernel", "encode_blocks_kernel", "crc32c_units_kernel",
+        "gather_slots_kernel", "decode_sparse_kernel")
+by = collections.defaultdict(list)
+for f in glob.glob(out + "/stats/*/*kernel_trace.csv"):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        if any(k.startswith(o) or o in k for o in ours):
+            by[(k, int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"])))].append(
+                (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+print("| kernel | workgroups | calls | avg ms | min ms |\n|---|---|---|---|---|")
+for (k, g), v in sorted(by.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
+    print("| %s | %d | %d | %.4f | %.4f |" % (k, g, len(v), sum(v) / len(v), min(v)))
+print("\n## HBM traffic per launch (separate --pmc passes; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md; the launches of the LARGEST grid of each kernel)\n")
 tr = collections.defaultdict(dict)
 for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for f in glob.glob(out + "/" + d + "/*/*counter_collection.csv"):
         acc = collections.defaultdict(float)
         disp = collections.defaultdict(set)
-        for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] != name:
-                continue
+        big = collections.defaultdict(int)
+        rows = [row for row in csv.DictReader(open(f)) if row["Counter_Name"] == name]
+        for row in rows:
             k = short(row["Kernel_Name"])
+            big[k] = max(big[k], int(row["Grid_Size"]))
+        for row in rows:
+            k = short(row["Kernel_Name"])
+            if int(row["Grid_Size"]) != big[k]:
+                continue  # (a smaller batch of the same kernel)
             acc[k] += float(row["Counter_Value"])
             disp[k].add(row["Dispatch_Id"])
         for k in acc:
