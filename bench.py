@@ -390,6 +390,7 @@ def per_class_rates(hip, corpus, ctx, dev, nb):
         def dec():
             ctx.decode_blocks(d_packed, d_in_off, d_sizes, nb, d_out, d_out_off, d_out_cap, d_out_len, d_status)
 
+        sp0, spn0 = ctx.kernel_ms(10)
         dec()
         ctx.sync()
         ctx.timing(True)
@@ -402,17 +403,22 @@ def per_class_rates(hip, corpus, ctx, dev, nb):
         dec_ms, _ = ctx.kernel_ms(0)
         idx_ms, _ = ctx.kernel_ms(4)
         dec2_ms, _ = ctx.kernel_ms(8)  # (the whole-block instantiation over the units the ring one passed on)
-        sp_ms, _ = ctx.kernel_ms(10)   # (the element-parallel kernel: units of few, long elements)
         ctx.timing(False)
-        dec_ms += dec2_ms + sp_ms
+        sp1, spn1 = ctx.kernel_ms(10)  # bytes / units the INDEX PASS decoded itself (few, long elements): a running count
+        sparse_bytes = (sp1 - sp0) / 4 if nb else 0  # (4 decodes since sp0: one warm-up, three timed)
+        dec_ms += dec2_ms
         assert bool(torch.equal(d_out, d_in)), cls
         u = nb * BLOCK
         out[cls] = {
             "decompress_GBps": round(u / t / 1e9, 1),
             "decode_kernel_ms": round(dec_ms, 3), "passed_on_units_kernel_ms": round(dec2_ms, 3),
-            "sparse_units_kernel_ms": round(sp_ms, 3),  # (decode_kernel_ms = all three decode launches)
+            # units of few, long elements are decoded inside the index pass (sparse_kernel.h): their bytes are not the
+            # decode launches', and the fraction below is (the other units' bytes) / (the decode launches' time)
+            "units_decoded_by_index_pass": int((spn1 - spn0) // 4), "their_bytes": int(sparse_bytes),
+            "decode_step_frac_of_hbm_peak": round((u + tot) / ((dec_ms + idx_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None,
             "index_pass_ms": round(idx_ms, 3),
-            "decode_frac_of_hbm_peak": round((u + tot) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if dec_ms else None,
+            "decode_frac_of_hbm_peak": (round((u + tot - sparse_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                        if dec_ms and u + tot - sparse_bytes > 0.05 * (u + tot) else None),
             "compress_GBps": round(u / (enc_ms * 1e-3) / 1e9, 1) if enc_ms else None,
             "compress_kernel_ms": round(enc_ms, 3),
             "compressed_over_uncompressed": round(tot / u, 3),
@@ -866,6 +872,7 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.sync()
+    sp0, spn0 = ctx.kernel_ms(10)  # (running counts: bytes / units the index pass decoded itself)
     ctx.timing(True)
     barrier()
     torch.cuda.synchronize()
@@ -879,8 +886,11 @@ def main():
     dec_ms, dec_launches = ctx.kernel_ms(0)   # decode_indexed_kernel (dominant)
     idx_ms, _ = ctx.kernel_ms(4)               # index_units_kernel
     dec2_ms, _ = ctx.kernel_ms(8)              # the whole-block instantiation over the units the ring one passed on
-    sp_ms, _ = ctx.kernel_ms(10)               # decode_sparse_kernel: units of few, long elements
+    sp1, spn1 = ctx.kernel_ms(10)
     ctx.timing(False)
+    # units of few, long elements are decoded inside the index pass (sparse_kernel.h): per step, their bytes and number
+    sparse_bytes = (sp1 - sp0) / max(args.steps, 1)
+    sparse_units = int((spn1 - spn0) // max(args.steps, 1))
     elapsed = shard.max_over_ranks(dist if world > 1 else None, elapsed, dev)
     # the side numbers are whole-job rates too: all ranks' bytes over the slowest rank's time
     t_enc = shard.max_over_ranks(dist if world > 1 else None, t_enc, dev)
@@ -932,9 +942,11 @@ def main():
     if rank == 0:
         u_bytes = nb * BLOCK
         value = world * u_bytes * args.steps / elapsed / 1e9
-        # every unit's bytes over ALL decode launches (the ring-window one, the one over the units it passes on, the
-        # element-parallel one): the ring kernel alone does not move all of them, so its duration alone would flatter it
-        achieved = (sum_c + u_bytes) / ((dec_ms + dec2_ms + sp_ms) * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        # the bytes of the units the two decode launches decode (the ring-window one and the one over the units it passes
+        # on) over their durations: the ring kernel alone does not move all of them, so its duration alone would flatter
+        # it -- and the units the index pass decodes itself (few, long elements) are not theirs at all
+        achieved = (sum_c + u_bytes - sparse_bytes) / ((dec_ms + dec2_ms) * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        step_achieved = (sum_c + u_bytes) / ((dec_ms + dec2_ms + idx_ms) * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         line = {
             "metric": "GB/s uncompressed throughput (compress + decompress), 4 GiB many-block corpus",
             "value": round(value, 3),
@@ -969,15 +981,19 @@ def main():
                 "traffic_source": measured_traffic(nb, args.only)[1],  # (null traffic: why)
                 "kernel": "decode_indexed_kernel<32768>",  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),  # (HIP events; rocprof's average for this kernel agrees)
-                "kernel_ms_all_decode_launches": round(dec_ms + dec2_ms + sp_ms, 4),  # what `achieved` divides by
-                "sparse_units_kernel_ms": round(sp_ms, 4),
+                "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
+                "units_decoded_by_index_pass": sparse_units,  # (few, long elements: sparse_kernel.h)
+                "their_bytes_per_launch": int(sparse_bytes),   # ... not in `achieved`'s numerator
+                # every unit's bytes over all three kernels of a step (index pass + both decode launches)
+                "step_achieved": round(step_achieved, 2), "step_frac": round(step_achieved / HBM_PEAK_GBPS, 5),
                 "index_pass_kernel_ms": round(idx_ms, 4),
                 "passed_on_units_kernel_ms": round(dec2_ms, 4),
                 # turns the indexed decoder gave up on after its bounded wait (must be 0; each costs ~30 ms and
                 # hands its unit to the one-pass kernel)
                 "decode_turns_given_up": give_ups,
                 "launches": dec_launches,
-                "algorithmic_bytes_per_launch": sum_c + u_bytes,
+                "algorithmic_bytes_per_launch": int(sum_c + u_bytes - sparse_bytes),
+                "algorithmic_bytes_per_step": sum_c + u_bytes,
             },
             "compress_GBps": round(world * u_bytes / t_enc / 1e9, 3),
             "compress_kernel_ms": round(enc_ms, 3),

@@ -197,8 +197,9 @@ int snappy_hip_ctx_launch_order(snappy_hip_ctx* ctx, int enable);
  * events on the launch stream (bench.py's roofline leg).  which: 0 block decode (the indexed
  * decode kernel, or the one-pass kernel when units carry per-unit kinds), 1 encode, 2 crc,
  * 3 pack, 4 decode index pass, 5 whole-stream decode pass, 6 framed chunk walk, 7 raw-buffer split rounds, 8 the
- * block decode's second launch (units the ring-window instantiation passes on), 10 the element-parallel decode of
- * units with few, long elements; 9 is a count, not a duration: turns
+ * block decode's second launch (units the ring-window instantiation passes on); 9 and 10 are counts, not durations:
+ * 10 the bytes (stream + output; *launches: how many) of units of few, long elements, which the index pass decodes itself,
+ * since the context was created; 9 turns
  * of the indexed decoder that were given up on after a bounded wait (0 on consistent input; such a unit is decoded by
  * the one-pass kernel) since the context was created.  Timing is recorded only between
  * snappy_hip_ctx_timing(ctx, 1) and (ctx, 0). */

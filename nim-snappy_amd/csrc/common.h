@@ -24,8 +24,9 @@ constexpr uint32_t kNeedsStreamKernel = 0x80000000u;
 constexpr uint32_t kNeedsOnePass = 0x80000001u;
 // Internal: the indexed decoder's ring-window instantiation passes the unit on to the whole-block one.
 constexpr uint32_t kNeedsWindow = 0x80000002u;
-// Internal: the index pass names the unit for the element-parallel decoder of units with few, long elements (sparse_kernel.h).
-constexpr uint32_t kNeedsSparse = 0x80000003u;
+// Internal: the index pass has decoded the unit itself (few, long elements: sparse_kernel.h); the decode launches leave it alone,
+// the last of them (the one-pass kernel over the declined units) makes it kOk.
+constexpr uint32_t kDoneEarly = 0x80000003u;
 
 enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
 

@@ -78,7 +78,11 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     // only units the block kernel handed over
     if (prm.status[unit_idx] != kNeedsStreamKernel) return;
   } else if (prm.only_status) {
-    if (prm.status[unit_idx] != prm.only_status) return;
+    const uint32_t st_now = prm.status[unit_idx];
+    // (a unit the index pass decoded itself carried kDoneEarly past the indexed decoder's launches: this launch is the
+    // last to look at every unit)
+    if (st_now == kDoneEarly && lane == 0) prm.status[unit_idx] = kOk;
+    if (st_now != prm.only_status) return;
   }
 
   const uint8_t* in0 = prm.in + prm.in_off[unit_idx];

@@ -55,6 +55,9 @@ __device__ __forceinline__ uint32_t idx_starts(uint32_t e) { return e & 0xffffu;
 __device__ __forceinline__ uint32_t idx_first_dst(uint32_t e) { return (e >> 16) + ((e & 0xffffu) ? 0u : 1u); }  // of the first start at or behind the entry's bytes
 __device__ __forceinline__ uint32_t idx_none(uint32_t next_dst) { return (next_dst ? next_dst - 1 : 0u) << 16; }
 constexpr uint32_t kSub = 16;                       // stream bytes per index entry (half a region)
+}  // namespace snappy_hip
+#include "sparse_kernel.h"  // (a unit of few, long elements is decoded by the wave that indexed it)
+namespace snappy_hip {
 constexpr uint32_t kSizeStride = 36;                // byte stride of a lane's row in the size table
 // Longest tag stream the indexed path takes (a valid 64 KiB block needs at most 76 490 bytes,
 // snappy/codec.nim:217); longer units go to the one-pass kernel.
@@ -85,11 +88,14 @@ struct IndexParams {
   int unit;
   uint32_t* blk_in;  // split mode: stream position (after the varint) where output block k starts
   const uint32_t* order;  // workgroup i takes unit order[i] (nullptr: unit i)
-  // Units of 2 .. sparse_max elements whose stream is longer than the indexed decoder's stream ring get the status
-  // kNeedsSparse: few, long elements (long literals, stretches of 64-byte copies) are the business of sparse_kernel.h.
-  // (One element: a literal, copied straight by the indexed decoder; a short stream of many copies: a period, written
-  // from one image there.)  0: never.
-  uint32_t sparse_max;
+  // Units of 2 .. kSparseMax elements whose stream is longer than the indexed decoder's stream ring are DECODED here, by
+  // the wave that has just indexed them: few, long elements (long literals, stretches of 64-byte copies) are the
+  // business of sparse_kernel.h.  (One element: a literal, copied straight by the indexed decoder; a short stream of many
+  // copies: a period, written from one image there.)  sparse = 0: never; out / out_off: where the units' output goes.
+  uint32_t sparse;
+  uint8_t* out;
+  const uint64_t* out_off;
+  uint32_t* sparse_counters;  // (may be nullptr) [0..1] 64-bit sum of such units' stream + output bytes, [2] their number
 };
 
 // Decode "the element that would start here" from its tag and the four bytes after it.
@@ -550,10 +556,21 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
-  if (prm.sparse_max && n > 4096) {
+  if (!SPLIT && prm.sparse && n > 4096) {
     uint32_t n_elem;
     (void)wave_excl_scan(n_elem_lane, lane, &n_elem);
-    if (n_elem >= 2 && n_elem <= prm.sparse_max) return finish(kNeedsSparse, op);
+    if (n_elem >= 2 && n_elem <= kSparseMax) {
+      static_assert(SPLIT || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
+      // (the index entries were written by other lanes of this wave: the stores are waited for -- one wave, one CU)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t st = sparse_decode_unit(in0, n, idx, prm.out + prm.out_off[u], op, s_tab);
+      if (st == kOk && prm.sparse_counters && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + op);
+        atomicAdd(prm.sparse_counters + 2, 1u);
+      }
+      return finish(st == kOk ? kDoneEarly : st, st == kInvalidInput ? 0 : op);
+    }
   }
   finish(kOk, op);
 }

@@ -26,7 +26,6 @@
 #include "encode_kernel.h"
 #include "framed_kernels.h"
 #include "index_kernel.h"
-#include "sparse_kernel.h"
 #include "split_kernels.h"
 
 using namespace snappy_hip;
@@ -112,7 +111,7 @@ struct DeviceGuard {
 
 }  // namespace
 
-constexpr int kTimeSlots = 11;  // snappy_hip_ctx_kernel_ms(which)
+constexpr int kTimeSlots = 10;  // snappy_hip_ctx_kernel_ms(which)
 struct snappy_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -122,7 +121,8 @@ struct snappy_hip_ctx {
   uint32_t crc_k32k = 0;           // x^(8 * 32768) mod P (decode2_kernel.h)
   uint32_t* d_seq_off = nullptr;   // [kSeqLen]
   uint32_t* d_seq_step = nullptr;  // [kSeqLen]
-  uint32_t* d_counters = nullptr;  // [16] [0] turns the indexed decoder gave up on (kernel_ms slot 9)
+  uint32_t* d_counters = nullptr;  // [16] [0] turns the indexed decoder gave up on (kernel_ms slot 9); [2..3] a 64-bit sum:
+                                   // stream + output bytes of the units the index pass decoded itself, [4] how many (slot 10)
   DevBuf ws[24];                   // grow-only workspace of the host-buffer API
   // page-locked staging ring of the host-buffer calls (stage_*, below): kStageSlots pieces, an event each
   uint8_t* stage = nullptr;
@@ -367,6 +367,12 @@ extern "C" double snappy_hip_ctx_kernel_ms(snappy_hip_ctx* c, int which, uint64_
     if (launches) *launches = v;
     return (double)v;
   }
+  if (which == 10) {  // not a duration either: bytes (stream + output) of the units the index pass decoded itself, and how many
+    uint32_t v[3] = {0, 0, 0};
+    if (hipMemcpy(v, c->d_counters + 2, 12, hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    if (launches) *launches = v[2];
+    return (double)(((uint64_t)v[1] << 32) | v[0]);
+  }
   if (which < 0 || which >= kTimeSlots) return 0;
   if (launches) *launches = c->ms_cnt[which];
   return c->ms_cnt[which] ? c->ms_sum[which] / (double)c->ms_cnt[which] : 0.0;
@@ -599,9 +605,12 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       HIP_TRY(hipMemsetAsync(d_stats, 0, 256, s));
       dp.stats = d_stats;
     }
-    // (units of few, long elements go to the element-parallel kernel, sparse_kernel.h: the index pass names them)
-    const bool sparse_on = kD2RingFirst && !dbg_env("SNAPPY_HIP_NO_RING") && !dbg_env("SNAPPY_HIP_NO_SPARSE");
-    ip.sparse_max = sparse_on ? kSparseMax : 0;
+    // (units of few, long elements are decoded by the index pass's own waves, sparse_kernel.h)
+    const bool sparse_on = kD2RingFirst && !dbg_env("SNAPPY_HIP_NO_RING") && !dbg_env("SNAPPY_HIP_NO_SPARSE") && !dbg_env("SNAPPY_HIP_NO_ONEPASS");
+    ip.sparse = sparse_on ? 1 : 0;
+    ip.out = d_out;
+    ip.out_off = d_out_off;
+    ip.sparse_counters = c->d_counters + 2;
     {
       LaunchTimer lt(c, s, 4);
       LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
@@ -634,28 +643,6 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
         LAUNCH((decode_indexed_kernel<kRingWin, true>), dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
       else
         LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
-    }
-    if (sparse_on) {  // the sparse units, as a list; the kernel's workgroups take them in turn (what it cannot do: kNeedsWindow)
-      void* d_sp;
-      if ((st = ws_get(c, 21, 8 + n_units * 4, &d_sp))) return st;
-      HIP_TRY(hipMemsetAsync(d_sp, 0, 8, s));
-      LAUNCH(status_list_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_status,
-             dp.order, n_units, kNeedsSparse, (uint32_t*)d_sp + 2);
-      SparseParams sp{};
-      sp.in = d_in;
-      sp.in_off = d_in_off;
-      sp.in_len = d_in_len;
-      sp.out = d_out;
-      sp.out_off = d_out_off;
-      sp.out_len = d_out_len;
-      sp.status = d_status;
-      sp.idx_off = (const uint64_t*)d_ioff;
-      sp.idx_stride = stride;
-      sp.idx = (const uint32_t*)d_idx;
-      sp.unit = unit;
-      sp.list = (const uint32_t*)d_sp + 2;
-      LaunchTimer lt(c, s, 10);
-      LAUNCH(decode_sparse_kernel, dim3((uint32_t)(n_units < 8192 ? n_units : 8192)), dim3(kSparseThreads), 0, s, sp);
     }
     if (ring_first) {  // the units it passed on, as a list
       void* d_pass;

@@ -22,36 +22,28 @@
 //      (device-scope loads, a fence and a barrier between two levels).
 //
 // Anything that does not fit -- more than kSparseLevels levels (deep chains are the indexed decoder's business) --
-// is handed to the whole-block instantiation of the indexed decoder (kNeedsWindow).  The index pass names the units
-// (kNeedsSparse: 2 .. kSparseMax elements, a stream longer than the indexed decoder's stream ring).
+// is handed to the whole-block instantiation of the indexed decoder (kNeedsWindow).
+//
+// There is no launch of its own: the INDEX PASS (index_kernel.h) counts a unit's elements, and the wave that has just
+// written the index of a unit of 2 .. kSparseMax elements (a stream longer than the indexed decoder's stream ring)
+// decodes it on the spot, in the LDS of its tables.  One wave per unit is what this procedure wants anyway -- a unit's
+// work is a chain of a few trips to memory, and what hides them is units in flight -- and its waits run beside the other
+// waves' table building, which is bound by the vector ALU.  (As a kernel behind the indexed decoder's launches it took
+// 0.43 ms of a 4 GiB step.)
+//
+// Included by index_kernel.h, behind the index entry helpers it uses.
 #pragma once
 
 #include "common.h"
-#include "index_kernel.h"
 
 namespace snappy_hip {
 
-constexpr uint32_t kSparseMax = 1024;    // elements
+constexpr uint32_t kSparseMax = 832;     // elements (its LDS arrays lie in the index pass's table: 8 448 bytes)
 constexpr uint32_t kSparseThreads = 64;  // ONE wave per unit: a unit's work is a chain of a few trips to memory, and what
                                          // hides them is many units in flight per CU (7 KiB of LDS each: 22)
 constexpr uint32_t kSparseLevels = 12;   // relaxation rounds = levels a unit may have
 constexpr uint32_t kSparseLong = 256;    // literals from here on are copied by the whole wave
 constexpr uint32_t kSparsePer = kSparseMax / kSparseThreads;  // elements per lane
-
-struct SparseParams {
-  const uint8_t* in;
-  const uint64_t* in_off;
-  const uint32_t* in_len;
-  uint8_t* out;
-  const uint64_t* out_off;
-  uint32_t* out_len;  // from the index pass (set to 0 here for a unit this kernel rejects)
-  uint32_t* status;
-  const uint64_t* idx_off;  // nullptr: u * idx_stride
-  uint64_t idx_stride;
-  const uint32_t* idx;
-  int unit;
-  const uint32_t* list;  // the units (status kNeedsSparse), list[-2] = how many
-};
 
 __device__ __forceinline__ uint4 ld16u(const uint8_t* p) {  // 16 bytes, any alignment
   uint4 v;
@@ -92,41 +84,33 @@ __device__ __forceinline__ void copy_apart64(uint8_t* dst, const uint8_t* src, u
   }
 }
 
-__global__ __launch_bounds__(kSparseThreads) void decode_sparse_kernel(SparseParams prm) {
-  __shared__ uint16_t s_dst[kSparseMax];  // first output byte of element e (the unit's total closes the last one)
-  __shared__ uint32_t s_src[kSparseMax];  // literal: stream position of its payload; copy: offset
-  __shared__ uint8_t s_lvl[kSparseMax];   // 0 literal, 1.. a copy's level, 255 not known yet
+// The LDS it works in: kSparseLds bytes, 4-byte aligned (the caller's; nothing of the caller's survives).
+constexpr uint32_t kSparseWork = 256;  // regions with element starts a unit may have
+constexpr uint32_t kSparseLds = kSparseMax * 4 + kSparseMax * 2 + kSparseMax + 2 * kSparseWork * 4 + 64 * 2 + 65 * 4 +
+                                (kSparseLevels + 2 + 1) * 4 + 16;
+// Decodes the unit whose tag stream is in0[0 .. n) (index entries idx[], total output bytes) into gout; ONE wave.
+// Returns kOk, kInvalidInput (a bad copy offset, decoder.nim:112) or kNeedsWindow (not for this procedure).
+// (inlined into its one caller: the compiler then knows the arrays are LDS)
+__device__ __forceinline__ uint32_t sparse_decode_unit(const uint8_t* in0, uint32_t n, const uint32_t* idx, uint8_t* gout,
+                                                       uint32_t total, uint32_t* lds) {
+  uint32_t* const s_src = lds;                                              // literal: stream position of its payload; copy: offset
+  uint32_t* const s_work = s_src + kSparseMax;                              // work lists (see below)
+  uint32_t* const s_lpre = s_work + 2 * kSparseWork;                        // running count of the long literals' 16-byte pieces
+  uint32_t* const s_hist = s_lpre + 65;
+  uint32_t* const s_nlong_p = s_hist + kSparseLevels + 2;
+  uint16_t* const s_dst = reinterpret_cast<uint16_t*>(s_nlong_p + 1);      // first output byte of element e (the total closes the last one)
+  uint16_t* const s_long = s_dst + kSparseMax;                              // long literals (element numbers)
+  uint8_t* const s_lvl = reinterpret_cast<uint8_t*>(s_long + 64);           // 0 literal, 1.. a copy's level, 255 not known yet
   // work lists, so that every trip to memory is made by 64 busy lanes: first the regions of the stream in which
   // elements start (region | first element's number << 16, and the region's index entry); the same 2 KiB later hold a
-  // relaxation round's results, and then the copies in the order of their levels (LDS is what bounds the units in
-  // flight per CU: 16 of them)
-  constexpr uint32_t kWork = 256;
-  __shared__ uint32_t s_work[2 * kWork];
+  // relaxation round's results, and then the copies in the order of their levels
+  constexpr uint32_t kWork = kSparseWork;
   static_assert(2 * kWork * 4 >= kSparseMax * 2, "the copies' order fits the region list's space");
-  uint8_t* const s_new = reinterpret_cast<uint8_t*>(s_work);  // (a relaxation round's results, before they replace the levels)
-  __shared__ uint16_t s_long[64];   // long literals (element numbers) ...
-  __shared__ uint32_t s_lpre[65];   // ... and the running count of their 16-byte pieces
-  __shared__ uint32_t s_nlong, s_hist[kSparseLevels + 2];
+  uint8_t* const s_new = reinterpret_cast<uint8_t*>(s_work);   // (a relaxation round's results, before they replace the levels)
   uint16_t* const s_order = reinterpret_cast<uint16_t*>(s_work);  // (the copies by level: the region list is done by then)
-  const uint32_t lane = threadIdx.x;
-  const uint32_t n_list = prm.list[-2];
-  for (uint32_t item = blockIdx.x; item < n_list; item += gridDim.x) {
-    const uint32_t u = prm.list[item];
-    const uint32_t total = prm.out_len[u];
-    const uint8_t* unit = prm.in + prm.in_off[u];
-    const uint32_t n_all = prm.in_len[u];
-    uint8_t* const gout = prm.out + prm.out_off[u];
-    const uint32_t* idx = prm.idx + (prm.idx_off ? prm.idx_off[u] : (uint64_t)u * prm.idx_stride);
-    uint32_t hdr = 0;
-    if (prm.unit == kUnitRaw) {  // skip the varint (validated by the index pass: at most 5 bytes)
-      uint32_t fb[5];
-#pragma unroll
-      for (uint32_t k = 0; k < 5; k++) fb[k] = unit[k < n_all ? k : n_all - 1];  // (one trip, not a chain of them)
-      while (hdr < 4 && (fb[hdr] & 0x80)) hdr++;
-      hdr++;
-    }
-    const uint8_t* const in0 = unit + hdr;
-    const uint32_t n = n_all - hdr;
+#define s_nlong (*s_nlong_p)
+  const uint32_t lane = lane_id();
+  {
     auto dst_at = [&](uint32_t e, uint32_t count) -> uint32_t { return e < count ? (uint32_t)s_dst[e] : total; };
     if (lane < kSparseLevels + 2) s_hist[lane] = 0;
     if (lane == 0) s_nlong = 0;
@@ -159,10 +143,7 @@ __global__ __launch_bounds__(kSparseThreads) void decode_sparse_kernel(SparsePar
         n_work += (uint32_t)__builtin_popcountll(ne);
       }
     }
-    if (count > kSparseMax || count == 0 || n_work > kWork) {  // (not what this kernel is for: the other decoder's)
-      if (lane == 0) prm.status[u] = kNeedsWindow;
-      continue;
-    }
+    if (count > kSparseMax || count == 0 || n_work > kWork) return kNeedsWindow;  // (not what this procedure is for)
     wave_fence();
     // ---- 1b. the elements: a lane per region of the list ----
     bool bad = false;
@@ -215,13 +196,7 @@ __global__ __launch_bounds__(kSparseThreads) void decode_sparse_kernel(SparsePar
       }
     }
     wave_fence();
-    if (ballot(bad)) {
-      if (lane == 0) {
-        prm.status[u] = kInvalidInput;
-        prm.out_len[u] = 0;  // (a failed unit reports no bytes, like the other kernels)
-      }
-      continue;
-    }
+    if (ballot(bad)) return kInvalidInput;
 #ifndef SPARSE_NO_LITS
     // ---- 2. literals: stream -> output ----
     const uint32_t nl_all = readfirst(s_nlong);
@@ -321,10 +296,7 @@ __global__ __launch_bounds__(kSparseThreads) void decode_sparse_kernel(SparsePar
       maxlvl = wmx > maxlvl ? wmx : maxlvl;
       settled = ballot(left) == 0;
     }
-    if (!settled || maxlvl > kSparseLevels) {  // deeper than this kernel goes: the indexed decoder's whole-block instantiation
-      if (lane == 0) prm.status[u] = kNeedsWindow;
-      continue;
-    }
+    if (!settled || maxlvl > kSparseLevels) return kNeedsWindow;  // deeper than this goes: the indexed decoder's whole-block instantiation
 #ifdef SPARSE_NO_COPIES
     maxlvl = 0;
 #endif
@@ -371,24 +343,10 @@ __global__ __launch_bounds__(kSparseThreads) void decode_sparse_kernel(SparsePar
         }
       }
     }
-    if (lane == 0) prm.status[u] = kOk;
-    wave_fence();  // (the LDS arrays are the next unit's)
+    wave_fence();
   }
-}
-
-// The units of one status (in launch order where there is one): list[-2] = how many.  One thread per unit.
-__global__ __launch_bounds__(256) void status_list_kernel(const uint32_t* status, const uint32_t* order, uint64_t n_units,
-                                                          uint32_t which, uint32_t* list) {
-  const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
-  const uint32_t u = i < n_units ? (order ? order[i] : (uint32_t)i) : 0;
-  const bool mine = i < n_units && status[u] == which;
-  const uint64_t m = ballot(mine);
-  if (m == 0) return;
-  const uint32_t lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(list - 2, (uint32_t)__builtin_popcountll(m));
-  base = readfirst(base);
-  if (mine) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = u;
+  return kOk;
+#undef s_nlong
 }
 
 }  // namespace snappy_hip
