@@ -115,6 +115,8 @@ constexpr int kTimeSlots = 10;  // snappy_hip_ctx_kernel_ms(which)
 struct snappy_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;  // work that runs beside the main stream's (a framed stream's stored chunks)
+  hipEvent_t side_done = nullptr;
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
   uint16_t* d_tag_lut = nullptr;   // [256] the decode front end's tag table (decode2_kernel.h)
@@ -241,6 +243,8 @@ extern "C" const char* snappy_hip_last_error(void) { return g_last_error.c_str()
 namespace {
 int ctx_init(snappy_hip_ctx* c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
@@ -318,6 +322,8 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_seq_off);
   (void)hipFree(c->d_seq_step);
   (void)hipFree(c->d_counters);
+  if (c->side_done) (void)hipEventDestroy(c->side_done);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -927,13 +933,12 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       return SNAPPY_HIP_DEVICE_ERROR;
     }
   }
-  if (res.n_comp) {  // compressed chunks: uncompress() each (snappy.nim:216), checksummed from the decoder's window
-    int st = decode_d(c, d_in, comp.in_off, comp.in_len, res.n_comp, kUnitRaw, nullptr, d_out, comp.out_off,
-                      comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr);
-    if (st) return st;
-  }
-  if (res.n_stored) {  // stored chunks: checksum the payload (snappy.nim:244) and copy it (:256)
-    if (check_integrity) {  // ... in one pass over the bytes
+  // The stored chunks are checksummed (snappy.nim:244) and copied (:256) in one pass over their bytes -- on a second
+  // stream, beside the compressed chunks' decode: the two touch different bytes, and the decode's index pass is bound
+  // by the vector ALU, not by memory.  (The lists are complete: the stream was waited for above.)
+  if (res.n_stored) {
+    hipStream_t s2 = c->side_stream;
+    if (check_integrity) {
       CrcParams cp{};
       cp.in = d_in;
       cp.off = stored.in_off;
@@ -945,14 +950,24 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       cp.copy_out = d_out;
       cp.copy_off = stored.out_off;
       cp.copy_cap = stored.out_cap;  // (0 for a chunk that is only checksummed)
-      LaunchTimer lt(c, s, 2);
-      LAUNCH(crc32c_units_kernel, dim3(res.n_stored), dim3(kCrcThreads), 0, s, cp);
+      LaunchTimer lt(c, s2, 2);
+      LAUNCH(crc32c_units_kernel, dim3(res.n_stored), dim3(kCrcThreads), 0, s2, cp);
     } else {
-      LAUNCH(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s, d_in, stored.in_off, stored.out_cap,
+      LAUNCH(copy_units_kernel, dim3(res.n_stored), dim3(256), 0, s2, d_in, stored.in_off, stored.out_cap,
                          stored.out_off, d_res, d_out);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->side_done, s2));
   }
+  if (res.n_comp) {  // compressed chunks: uncompress() each (snappy.nim:216), checksummed from the decoder's window
+    int st = decode_d(c, d_in, comp.in_off, comp.in_len, res.n_comp, kUnitRaw, nullptr, d_out, comp.out_off,
+                      comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr);
+    if (st) {
+      if (res.n_stored) (void)hipStreamSynchronize(c->side_stream);
+      return st;
+    }
+  }
+  if (res.n_stored) HIP_TRY(hipStreamWaitEvent(s, c->side_done, 0));
   FrameVerdictParams vp{};
   vp.comp = comp;
   vp.stored = stored;
