@@ -264,6 +264,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   };
   bool strad_before = false;  // SPLIT: a straddling element in an earlier chunk
   uint32_t n_elem_lane = 0;   // elements that start in my regions, over all chunks (sparse verdict)
+  uint32_t first_out = 0, first_n = 0;  // (uniform) the first region's chain: output bytes, elements
   unsigned long long tA = 0, tW = 0, tC = 0, tt0 = 0, tt1 = 0, tt2 = 0;  // DEBUG (SPLIT, prm.idx != nullptr)
   const bool dbgt = SPLIT && prm.idx != nullptr;
   if (SPLIT && wave == 0) post(0, 0, 0, 0, false);
@@ -524,6 +525,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     }
     }
     n_elem_lane += nelem_here;
+    if (!SPLIT && c0 == 0) {
+      first_out = readlane(out_here, 0);
+      first_n = readlane(nelem_here, 0);
+    }
     op += tot;
     if (SPLIT) {
       const bool strad = strad_before || ballot(straddle) != 0;
@@ -556,20 +561,39 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
   if (exact && op != limit) return finish(kInvalidInput, 0);  // snappy.nim:107-108
-  if (!SPLIT && prm.sparse && n > 4096) {
-    uint32_t n_elem;
-    (void)wave_excl_scan(n_elem_lane, lane, &n_elem);
-    if (n_elem >= 2 && n_elem <= kSparseMax) {
-      static_assert(SPLIT || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
-      // (the index entries were written by other lanes of this wave: the stores are waited for -- one wave, one CU)
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t st = sparse_decode_unit(in0, n, idx, prm.out + prm.out_off[u], op, s_tab);
-      if (st == kOk && prm.sparse_counters && lane == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + op);
-        atomicAdd(prm.sparse_counters + 2, 1u);
+  if (!SPLIT && prm.sparse) {
+    // Three kinds of unit this wave finishes itself, in the LDS of its tables (sparse_kernel.h): one literal; a literal
+    // and copies of one offset (a period); few, long elements.  Their status, kDoneEarly, is carried past the indexed
+    // decoder's launches.
+    static_assert(SPLIT || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
+    static_assert(SPLIT || sizeof(s_tab) >= 4096 + 4096 + 32, "... and the period's stream and image");
+    uint8_t* const gptr = prm.out + prm.out_off[u];
+#ifndef IDX_NO_EARLY_LIT
+    if (first_n == 1 && first_out == op) {  // the first element writes every byte: a literal (a copy cannot be first)
+      const uint32_t hi6 = (uint32_t)in0[0] >> 2;
+      early_literal_unit(in0 + 1 + (hi6 >= 60 ? hi6 - 59 : 0), gptr, op);
+      return finish(kDoneEarly, op);
+    }
+#endif
+    if (n <= 4096) {
+#ifndef IDX_NO_EARLY_PERIOD
+      wave_fence();
+      if (early_period_unit(in0, n, gptr, op, s_tab)) return finish(kDoneEarly, op);
+#endif
+    } else {
+      uint32_t n_elem;
+      (void)wave_excl_scan(n_elem_lane, lane, &n_elem);
+      if (n_elem >= 2 && n_elem <= kSparseMax) {
+        // (the index entries were written by other lanes of this wave: the stores are waited for -- one wave, one CU)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t st = sparse_decode_unit(in0, n, idx, gptr, op, s_tab);
+        if (st == kOk && prm.sparse_counters && lane == 0) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + op);
+          atomicAdd(prm.sparse_counters + 2, 1u);
+        }
+        return finish(st == kOk ? kDoneEarly : st, st == kInvalidInput ? 0 : op);
       }
-      return finish(st == kOk ? kDoneEarly : st, st == kInvalidInput ? 0 : op);
     }
   }
   finish(kOk, op);

@@ -349,4 +349,108 @@ __device__ __forceinline__ uint32_t sparse_decode_unit(const uint8_t* in0, uint3
 #undef s_nlong
 }
 
+// ---- two more kinds of unit the index pass's wave finishes itself (the indexed decoder has the same two fast paths, for
+// ---- when this one is switched off; here their trips to memory run beside the other waves' table building, and a
+// ---- framed stream's checksum of them can start while the indexed decoder works on the rest) ------------------------
+
+// The unit is ONE literal (what encodeBlock makes of incompressible data, encoder.nim:249-253): its payload, `total`
+// bytes at src, goes straight to gout.  One wave; destination-aligned 16-byte pieces, eight in flight a lane.
+__device__ __forceinline__ void early_literal_unit(const uint8_t* src, uint8_t* gout, uint32_t total) {
+  const uint32_t lane = lane_id();
+  const uint32_t head = (uint32_t)((16 - ((uintptr_t)gout & 15)) & 15);
+  const uint32_t hd = head < total ? head : total;
+  if (lane < hd) gout[lane] = src[lane];
+  const uint32_t body = (total - hd) & ~15u;
+  for (uint32_t i = lane * 16; i < body; i += 8 * 64 * 16) {
+    uint32_t ix[8];
+    uint4 v[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) ix[q] = i + q * 1024 < body ? i + q * 1024 : i;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) v[q] = ld16u(src + hd + ix[q]);
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) *reinterpret_cast<uint4*>(gout + hd + ix[q]) = v[q];
+  }
+  if (hd + body + lane < total) gout[hd + body + lane] = src[hd + body + lane];
+}
+
+// The unit is one literal followed by copies that all have ONE offset (what encodeBlock makes of a period -- zeros, a
+// repeating pattern, a ramp: every match is found at the same distance and emitCopy cuts it into copy2 elements,
+// encoder.nim:97-120): its output is periodic behind the literal, out[x] = out[x - offset], so it is written from one
+// image of the period.  The index pass has validated the stream as a sequence of elements and its total, so "every third
+// byte behind the literal is a copy2 tag with that offset" proves that those are the element starts (decoder.nim:112:
+// 1 <= offset <= the literal's length).  One wave; lds: 8 224 bytes (the stream, at most 4 KiB, and the image).
+// Returns false if the unit is not of this kind (nothing written).
+__device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n, uint8_t* gout, uint32_t total, uint32_t* lds) {
+  const uint32_t lane = lane_id();
+  if (n > 4096 || n < 5 || ((uintptr_t)gout & 15) != 0) return false;
+  uint8_t* const s_str = reinterpret_cast<uint8_t*>(lds);
+  uint8_t* const s_rep = s_str + 4096;
+  for (uint32_t i = lane * 16; i < n; i += 64 * 16) {  // (the whole stream: at most four pieces a lane)
+    if (i + 16 <= n) {
+      *reinterpret_cast<uint4*>(s_str + i) = ld16u(in0 + i);
+    } else {
+      for (uint32_t k = i; k < n; k++) s_str[k] = in0[k];
+    }
+  }
+  wave_fence();
+  const uint32_t tag = s_str[0], hi6 = tag >> 2;
+  const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
+  if ((tag & 3) != 0 || 1 + lenlen + 3 > n) return false;
+  uint32_t L0 = hi6 + 1;
+  if (lenlen) {
+    uint32_t b = 0;
+    for (uint32_t k = 0; k < lenlen; k++) b |= (uint32_t)s_str[1 + k] << (8 * k);
+    L0 = b + 1;
+  }
+  const uint32_t h = 1 + lenlen;
+  if (L0 == 0 || L0 >= total || h + L0 + 3 > n || (n - h - L0) % 3 != 0) return false;
+  const uint32_t q0 = h + L0;  // the first copy
+  const uint32_t roff = s_str[q0 + 1] | ((uint32_t)s_str[q0 + 2] << 8);
+  if ((s_str[q0] & 3) != 2 || roff < 1 || roff > L0 || roff > 4096) return false;
+  const uint32_t nrec = (n - q0) / 3;
+  bool ok = true;
+  for (uint32_t k = lane; k < nrec; k += 64) {
+    const uint32_t t = q0 + 3 * k;
+    ok = ok && (s_str[t] & 3) == 2 && (s_str[t + 1] | ((uint32_t)s_str[t + 2] << 8)) == roff;
+  }
+  if (ballot(!ok)) return false;
+  // image of the period: rep[i] = out[L0 - offset + i mod offset] for i < M + 16, M a multiple of the offset of about 4 KiB
+  const uint32_t M = roff * (4096 / roff);  // (> 1024: the writer's phase advances by 1024 a trip)
+  const uint32_t pb = q0 - roff;            // stream position of the period's first byte
+  for (uint32_t i0 = lane * 16; i0 < M + 16; i0 += 64 * 16) {
+    uint32_t r = i0 % roff;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      s_rep[i0 + j] = s_str[pb + r];
+      r = r + 1 == roff ? 0 : r + 1;
+    }
+  }
+  wave_fence();
+  const uint32_t* const rep32 = reinterpret_cast<const uint32_t*>(s_rep);
+  uint32_t x = lane * 16;
+  uint32_t ix = x >= L0 ? (x - L0) % M : 0;  // phase of x in the image (kept up to date from the first x >= L0 on)
+  bool phased = x >= L0;
+  for (; x < total; x += 1024) {
+    if (x >= L0 && !phased) {
+      ix = (x - L0) % M;
+      phased = true;
+    }
+    if (x >= L0 && x + 16 <= total) {
+      const uint32_t a = ix >> 2, sh8 = (ix & 3) * 8;
+      const uint32_t r0 = rep32[a], r1 = rep32[a + 1], r2 = rep32[a + 2], r3 = rep32[a + 3], r4 = rep32[a + 4];
+      *reinterpret_cast<uint4*>(gout + x) = make_uint4(__funnelshift_r(r0, r1, sh8), __funnelshift_r(r1, r2, sh8),
+                                                       __funnelshift_r(r2, r3, sh8), __funnelshift_r(r3, r4, sh8));
+    } else {
+      for (uint32_t k = x; k < x + 16 && k < total; k++)
+        gout[k] = k < L0 ? s_str[h + k] : s_rep[(k - L0) % M];
+    }
+    if (phased) {
+      ix += 1024;
+      ix = ix >= M ? ix - M : ix;
+    }
+  }
+  return true;
+}
+
 }  // namespace snappy_hip
