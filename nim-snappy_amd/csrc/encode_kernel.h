@@ -136,9 +136,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
 
   // ---- output: elements collect in s_ob and leave with wide stores ----------------------------
   // Everything that is written goes through drain() below, which has the one flush in the kernel.
-  bool finished = false;                // the parse is over; what is pending is all that is left
+  uint32_t finished = 0;                // the parse is over; what is pending is all that is left
   // pending output, written in this order:
-  bool dpend = false;                   // (1) the elements of a fresh round (position-parallel)
+  uint32_t dpend = 0;                   // (1) the elements of a fresh round (position-parallel)
   uint64_t dp_ms = 0;                   //     lanes where a copy starts
   bool dp_lit = false;                  //     per lane: its byte is a literal byte
   uint32_t dp_len = 0, dp_off = 0, dp_byte = 0;  // per lane: copy length, copy offset, the byte at the lane's position
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   if (lane == 0) s_walk = 1;
 #endif
   wave_fence();
-  bool cold_any = false;                // one of (2)-(4) is set
+  uint32_t cold_any = 0;                // one of (2)-(4) is set
   ColdU32 lit_from{&s_cold[0]}, lit_len{&s_cold[1]};    // (2) one literal ...
   ColdU32 cp_off{&s_cold[2]}, cp_len{&s_cold[3]};       // (3) ... one copy ...
   ColdU32 lit2_from{&s_cold[4]}, lit2_len{&s_cold[5]};  // (4) ... and the block's final literal (encoder.nim:249-253)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   // CONTINUING round (idx0 > 0): a scan that found nothing among its first 47 probes; lanes take
   // the next 64 entries of the probe sequence (positions further and further apart), straight
   // from memory; one match ends the round.
-  bool has0 = false;        // fresh round after a copy: lanes 0,1 are the insert of ip-1 and the probe at ip = s0-1
+  uint32_t has0 = 0;        // fresh round after a copy: lanes 0,1 are the insert of ip-1 and the probe at ip = s0-1
   uint32_t next_emit = 0;   // start of the pending literal
   uint32_t s0 = 1;          // position of probe 0 of the current literal scan
   uint32_t idx0 = 0;        // index into the probe sequence of a continuing round's first lane
