@@ -145,9 +145,7 @@ constexpr uint32_t kScanThreads = 1024;
 // offsets[0] = base, offsets[i+1] = offsets[i] + sizes[i].  One workgroup; a pass takes 8 192 sizes (eight
 // consecutive ones per thread: their prefix in registers, one DPP scan of the threads' sums per wave, the
 // sixteen wave sums through LDS), so 65 536 sizes are eight passes of two barriers each.
-__global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t* sizes,
-                                                                  uint64_t n, uint64_t base,
-                                                                  uint64_t* offsets) {
+__device__ __forceinline__ void scan_sizes_body(const uint32_t* sizes, uint64_t n, uint64_t base, uint64_t* offsets) {
   constexpr uint32_t kPer = 8;
   // (64-bit sums throughout: the sizes of pack and of the frame scans are below 2^17, but the kernel also scans the
   // tile sums of untrusted raw streams and a caller's sizes -- a pass of 8 192 of those can exceed 2^32, and the
@@ -157,11 +155,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t
   if (t == 0) offsets[0] = base;
   uint64_t carry = base;  // (every thread keeps it: the pass total is read by all)
   uint32_t par = 0;
+  auto load = [&](uint64_t c, uint32_t* r) {
+    const uint64_t i0 = c + (uint64_t)t * kPer;
+    if (i0 + kPer <= n && (((uintptr_t)(sizes + i0)) & 15) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4*>(sizes + i0), b = *reinterpret_cast<const uint4*>(sizes + i0 + 4);
+      r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; k++) r[k] = i0 + k < n ? sizes[i0 + k] : 0;
+    }
+  };
+  uint32_t nx[kPer];
+  load(0, nx);
   for (uint64_t c = 0; c < n; c += (uint64_t)kScanThreads * kPer, par ^= 1) {
     const uint64_t i0 = c + (uint64_t)t * kPer;
     uint64_t v[kPer];
 #pragma unroll
-    for (uint32_t k = 0; k < kPer; k++) v[k] = i0 + k < n ? sizes[i0 + k] : 0;
+    for (uint32_t k = 0; k < kPer; k++) v[k] = nx[k];
+    if (c + (uint64_t)kScanThreads * kPer < n) load(c + (uint64_t)kScanThreads * kPer, nx);  // (the next pass's, under way during this one)
 #pragma unroll
     for (uint32_t k = 1; k < kPer; k++) v[k] += v[k - 1];
     uint64_t incl = v[kPer - 1];  // inclusive prefix sum over the wave
@@ -186,6 +197,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t
       if (i0 + k < n) offsets[i0 + k + 1] = at + v[k];
     carry += pass_total;
   }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_sizes_kernel(const uint32_t* sizes, uint64_t n, uint64_t base,
+                                                                  uint64_t* offsets) {
+  scan_sizes_body(sizes, n, base, offsets);
+}
+
+// Up to four such scans of n sizes each, one workgroup per scan (the framed stream's three chunk-list scans).
+struct ScanJobs {
+  const uint32_t* sizes[4];
+  uint64_t* offsets[4];
+  uint64_t n;
+};
+__global__ __launch_bounds__(kScanThreads) void scan_sizes_jobs_kernel(ScanJobs j) {
+  scan_sizes_body(j.sizes[blockIdx.x], j.n, 0, j.offsets[blockIdx.x]);
 }
 
 // Copy slot i (src = slots + i*stride, sizes[i] bytes) to out + offsets[i].

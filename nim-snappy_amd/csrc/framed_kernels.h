@@ -568,11 +568,23 @@ __global__ __launch_bounds__(1024) void frame_verdict_kernel(FrameVerdictParams 
   if (threadIdx.x == 0) s_first = ~0ull;
   __syncthreads();
   unsigned long long mine = ~0ull;
-  for (uint32_t i = threadIdx.x; i < r.n_comp; i += blockDim.x) {
-    const bool fail = p.comp_status[i] != kOk || (p.check_integrity && p.comp_crc[i] != p.comp.crc[i]);
-    if (fail) {
-      const unsigned long long key = ((unsigned long long)p.comp.seq[i] << 32) | i;
-      mine = key < mine ? key : mine;
+  for (uint32_t i0 = threadIdx.x; i0 < r.n_comp; i0 += 8 * blockDim.x) {  // (eight entries' loads in flight together)
+    uint32_t st[8], got[8], want[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t i = i0 + k * blockDim.x;
+      const bool in = i < r.n_comp;
+      st[k] = in ? p.comp_status[i] : (uint32_t)kOk;
+      got[k] = in && p.check_integrity ? p.comp_crc[i] : 0;
+      want[k] = in && p.check_integrity ? p.comp.crc[i] : 0;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t i = i0 + k * blockDim.x;
+      if (st[k] != kOk || got[k] != want[k]) {
+        const unsigned long long key = ((unsigned long long)p.comp.seq[i] << 32) | i;
+        mine = key < mine ? key : mine;
+      }
     }
   }
   for (uint32_t i = threadIdx.x; i < r.n_stored; i += blockDim.x) {

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <thread>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -117,6 +118,7 @@ struct snappy_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // work that runs beside the main stream's (a framed stream's stored chunks)
   hipEvent_t side_done = nullptr;
+  hipEvent_t side_fork = nullptr;  // (recorded on the main stream: what the side stream's work waits for)
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
   uint16_t* d_tag_lut = nullptr;   // [256] the decode front end's tag table (decode2_kernel.h)
@@ -243,8 +245,13 @@ extern "C" const char* snappy_hip_last_error(void) { return g_last_error.c_str()
 namespace {
 int ctx_init(snappy_hip_ctx* c) {
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  {  // (least priority: the main stream's small launches are not to queue behind the side stream's workgroups)
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
+  }
   HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
@@ -323,6 +330,7 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_seq_step);
   (void)hipFree(c->d_counters);
   if (c->side_done) (void)hipEventDestroy(c->side_done);
+  if (c->side_fork) (void)hipEventDestroy(c->side_fork);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -521,8 +529,10 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
              const uint32_t* d_in_len, uint64_t n_units, int unit, const uint8_t* d_kind,
              uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
              uint32_t* d_out_len, uint32_t* d_status, bool stream_pass, hipStream_t s,
-             uint32_t* d_crc = nullptr) {
-  if (n_units == 0) return SNAPPY_HIP_OK;
+             uint32_t* d_crc = nullptr, const std::function<int()>* beside_index = nullptr) {
+  // (beside_index: work the caller wants launched on another stream right in front of the index pass, the first
+  // launch here that fills the GPU -- launched earlier, its workgroups hold up the small launches in front of it)
+  if (n_units == 0) return beside_index ? (*beside_index)() : SNAPPY_HIP_OK;
   if (n_units > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
   DecodeParams p{};
   p.in = d_in;
@@ -540,6 +550,10 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
   const bool v1 = d_kind != nullptr || dbg_env("SNAPPY_HIP_DECODE_V1") != nullptr;
   void* d_done = nullptr;  // per unit: the indexed decode kernel has written its CRC
   if (v1) {
+    if (beside_index) {
+      const int hs = (*beside_index)();
+      if (hs) return hs;
+    }
     LaunchTimer lt(c, s, 0);
     LAUNCH(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
   } else {
@@ -617,6 +631,8 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     ip.out = d_out;
     ip.out_off = d_out_off;
     ip.sparse_counters = c->d_counters + 2;
+    if (beside_index && (st = (*beside_index)())) return st;
+    beside_index = nullptr;
     {
       LaunchTimer lt(c, s, 4);
       LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
@@ -865,9 +881,14 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
       fp.irregular = d_flags;
       const uint32_t grid = (uint32_t)((H + 255) / 256);
       LAUNCH(frame_fill_kernel, dim3(grid), dim3(256), 0, s, fp);
-      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_ulen, (uint64_t)H, (uint64_t)0, d_out_at);
-      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_comp, (uint64_t)H, (uint64_t)0, d_comp_at);
-      LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_is_stored, (uint64_t)H, (uint64_t)0, d_stored_at);
+      {  // the three scans side by side, a workgroup each
+        ScanJobs sj{};
+        sj.sizes[0] = d_ulen, sj.offsets[0] = d_out_at;
+        sj.sizes[1] = d_is_comp, sj.offsets[1] = d_comp_at;
+        sj.sizes[2] = d_is_stored, sj.offsets[2] = d_stored_at;
+        sj.n = (uint64_t)H;
+        LAUNCH(scan_sizes_jobs_kernel, dim3(3), dim3(kScanThreads), 0, s, sj);
+      }
       FrameScatterParams xp{};
       xp.in = d_in;
       xp.n = n;
@@ -936,7 +957,8 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
   // The stored chunks are checksummed (snappy.nim:244) and copied (:256) in one pass over their bytes -- on a second
   // stream, beside the compressed chunks' decode: the two touch different bytes, and the decode's index pass is bound
   // by the vector ALU, not by memory.  (The lists are complete: the stream was waited for above.)
-  if (res.n_stored) {
+  const std::function<int()> launch_stored = [&]() -> int {
+    if (!res.n_stored) return SNAPPY_HIP_OK;
     hipStream_t s2 = c->side_stream;
     if (check_integrity) {
       CrcParams cp{};
@@ -958,10 +980,14 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->side_done, s2));
-  }
-  if (res.n_comp) {  // compressed chunks: uncompress() each (snappy.nim:216), checksummed from the decoder's window
+    return SNAPPY_HIP_OK;
+  };
+  if (!res.n_comp) {
+    const int st = launch_stored();
+    if (st) return st;
+  } else {  // compressed chunks: uncompress() each (snappy.nim:216), checksummed from the decoder's window
     int st = decode_d(c, d_in, comp.in_off, comp.in_len, res.n_comp, kUnitRaw, nullptr, d_out, comp.out_off,
-                      comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr);
+                      comp.out_cap, comp_len, comp_status, true, s, check_integrity ? comp_crc : nullptr, &launch_stored);
     if (st) {
       if (res.n_stored) (void)hipStreamSynchronize(c->side_stream);
       return st;
