@@ -414,7 +414,19 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
             out_abs = rs + ex;
           }
         }
-        const uint32_t prev = lane_prev_u32(out_abs);
+        // what arrives at my region is the exit of the nearest region in front of me that the chain really enters: a
+        // region it passes over (has == false: a long literal's payload) hands on what it got, and lane by lane that
+        // takes a round per region passed -- up to 63 for a chunk with a long literal in it -- so those are skipped
+        const uint64_t hm = ballot(has);
+        uint32_t prev;
+        if (hm == ~0ull) {
+          prev = lane_prev_u32(out_abs);
+        } else {
+          const uint64_t below = hm & ((1ull << lane) - 1);
+          const uint32_t j = below ? 63 - (uint32_t)__builtin_clzll(below) : 0;
+          const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)out_abs);
+          prev = below ? v : e_abs;
+        }
         const uint32_t nin = lane == 0 ? e_abs : prev;
         const bool changed = nin != in_abs;
         in_abs = nin;
@@ -568,17 +580,27 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     static_assert(SPLIT || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
     static_assert(SPLIT || sizeof(s_tab) >= 4096 + 4096 + 32, "... and the period's stream and image");
     uint8_t* const gptr = prm.out + prm.out_off[u];
+    auto count_early = [&]() {  // (bench.py: the bytes of these units are this pass's, not the indexed decoder's)
+      if (prm.sparse_counters && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + op);
+        atomicAdd(prm.sparse_counters + 2, 1u);
+      }
+    };
 #ifndef IDX_NO_EARLY_LIT
     if (first_n == 1 && first_out == op) {  // the first element writes every byte: a literal (a copy cannot be first)
       const uint32_t hi6 = (uint32_t)in0[0] >> 2;
       early_literal_unit(in0 + 1 + (hi6 >= 60 ? hi6 - 59 : 0), gptr, op);
+      count_early();
       return finish(kDoneEarly, op);
     }
 #endif
     if (n <= 4096) {
 #ifndef IDX_NO_EARLY_PERIOD
       wave_fence();
-      if (early_period_unit(in0, n, gptr, op, s_tab)) return finish(kDoneEarly, op);
+      if (early_period_unit(in0, n, gptr, op, s_tab)) {
+        count_early();
+        return finish(kDoneEarly, op);
+      }
 #endif
     } else {
       uint32_t n_elem;
@@ -588,10 +610,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const uint32_t st = sparse_decode_unit(in0, n, idx, gptr, op, s_tab);
-        if (st == kOk && prm.sparse_counters && lane == 0) {
-          atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + op);
-          atomicAdd(prm.sparse_counters + 2, 1u);
-        }
+        if (st == kOk) count_early();
         return finish(st == kOk ? kDoneEarly : st, st == kInvalidInput ? 0 : op);
       }
     }
