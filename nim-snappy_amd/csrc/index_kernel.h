@@ -314,33 +314,47 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
       // ---- right-to-left pass over my 32 positions --------------------------------------------
       // (interior = the whole step and the longest short element behind it lie inside the stream:
       // the bounds checks of the short forms fold away, which is one instruction in six)
+      // The entry of position k needs the finished entry of k + size: a chain of LDS round trips down the region.  Two
+      // things keep it short.  The tag table is read for eight positions at a time (those reads depend on nothing).
+      // And the table read of position k - 1 is issued BEFORE the entry of k is written: an element is at least two
+      // bytes (a tag and a byte of literal or offset), so k - 1 never needs k's entry, only k + 1's and later ones --
+      // two positions' round trips are in flight at any time.  (The compiler cannot know that and keeps the program's
+      // order of LDS accesses: read, wait, write, read, wait: 64 trips a region before, about 24 now.)
       auto tabulate = [&](auto interior_c) {
       constexpr bool kInterior = decltype(interior_c)::value;
-#pragma unroll
-      for (int k = kRegion - 1; k >= 0; k--) {
+      struct Info {
+        uint32_t L, out_code, Ls, szb, ridx;
+        bool inside, ok, inreg;
+      };
+      auto tag_of = [&](int k) -> uint32_t {
+        const uint32_t lo = w[k >> 2];
+        return (lo >> ((k & 3) * 8)) & 0xff;
+      };
+      // what position k's own element says (e = its tag's table entry)
+      auto make_info = [&](int k, uint32_t e) -> Info {
+        Info f;
         const uint32_t p = rs + k;
-        // (selects only: a divergent branch per position costs more than the work it skips)
-        const uint32_t lo = w[k >> 2], hi = w[(k >> 2) + 1], hi2 = w[(k >> 2) + 2];
-        const uint32_t sh8 = (k & 3) * 8;
-        const uint32_t d0 = sh8 ? __funnelshift_r(lo, hi, sh8) : lo;   // bytes k..k+3
-        const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
-        const uint32_t tag = d0 & 0xff;
-        const uint32_t b14 = (d0 >> 8) | (d1 << 24);
-        const bool inside = kInterior || p < n;
-        const uint32_t e = s_lut[tag];
+        f.inside = kInterior || p < n;
         uint32_t L = e & 127, size = (e >> 7) & 127;
-        bool ok = kInterior || (inside && p + size <= n);  // every short form: the element must end inside the stream
+        bool ok = kInterior || (f.inside && p + size <= n);  // every short form: the element must end inside the stream
         // what the entry of an element that leaves the region looks like: the short forms (at most 65
         // bytes) exit at nx itself, with their own length and a size that fits a byte
         uint32_t nx = (uint32_t)k + size;
         uint32_t out_code = nx, Ls = L, szb = size;
-        if (__builtin_expect(ballot(inside && (e >> 14)) != 0, 0)) {  // a literal with length bytes somewhere (rare in text)
-          const uint32_t rem = inside ? n - p - 1 : 0;
+        if (__builtin_expect(ballot(f.inside && (e >> 14)) != 0, 0)) {  // a literal with length bytes somewhere (rare in text)
+          // (selects only: a divergent branch per position costs more than the work it skips)
+          const uint32_t lo = w[k >> 2], hi = w[(k >> 2) + 1], hi2 = w[(k >> 2) + 2];
+          const uint32_t sh8 = (k & 3) * 8;
+          const uint32_t d0 = sh8 ? __funnelshift_r(lo, hi, sh8) : lo;   // bytes k..k+3
+          const uint32_t d1 = sh8 ? __funnelshift_r(hi, hi2, sh8) : hi;  // bytes k+4..k+7
+          const uint32_t tag = d0 & 0xff;
+          const uint32_t b14 = (d0 >> 8) | (d1 << 24);
+          const uint32_t rem = f.inside ? n - p - 1 : 0;
           const uint32_t lenlen = (tag >> 2) - 59;  // 1..4 where it applies
           const uint32_t m = 0xffffffffu >> (32 - 8 * (lenlen & 7 ? (lenlen & 7) : 4));
           const uint32_t llen = (b14 & m) + 1;
           const bool lok = rem >= 61 && llen != 0 && !(rem - lenlen < llen);  // decoder.nim:54-57, :67-68, :78
-          const bool ll = inside && (e >> 14);
+          const bool ll = f.inside && (e >> 14);
           L = ll ? llen : L;
           size = ll ? 1 + lenlen + llen : size;
           ok = ll ? lok : ok;
@@ -352,19 +366,41 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
           Ls = L < kOutSat ? L : kOutSat;
           szb = size < 255 ? size : 255;
         }
-        const bool inreg = ok && nx < kRegion;
-        const uint32_t tn = s_tab[row + (inreg ? nx : (uint32_t)k)];
-        // the fields are additive along the chain: same exit, one more element, L more bytes
-        // (an error or end entry keeps its exit code; in-region lengths are <= 64, so the 17-bit
-        // sum cannot overflow past the saturated terminal element)
-        const uint32_t t_in = tn + ((1u << 10) | (L << 15));
-        const uint32_t t_out_of = out_code | (1u << 10) | (Ls << 15);
-        const uint32_t t = !inside ? t_pack(kExitEnd, 0, 0)
-                                   : (!ok ? t_pack(kExitErr, 0, 0) : (inreg ? t_in : t_out_of));
-        szb = ok ? szb : 255;
-        s_tab[row + k] = t;
-        if (SPLIT) s_sz[row8 + k] = (uint8_t)szb;
-        else szp[k >> 2] |= szb << (8 * (k & 3));
+        f.L = L, f.out_code = out_code, f.Ls = Ls, f.szb = szb, f.ok = ok;
+        f.inreg = ok && nx < kRegion;
+        f.ridx = f.inreg ? nx : (uint32_t)k;
+        return f;
+      };
+#pragma unroll
+      for (int kb = kRegion - 8; kb >= 0; kb -= 8) {
+        uint32_t ee[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) ee[j] = s_lut[tag_of(kb + j)];
+        Info cur = make_info(kb + 7, ee[7]);
+        uint32_t tn = s_tab[row + cur.ridx];
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+          const int k = kb + j;
+          Info nxt = cur;
+          uint32_t tn_nxt = 0;
+          if (j > 0) {
+            nxt = make_info(k - 1, ee[j - 1]);
+            tn_nxt = s_tab[row + nxt.ridx];  // (before k's entry is written: see above)
+          }
+          // the fields are additive along the chain: same exit, one more element, L more bytes
+          // (an error or end entry keeps its exit code; in-region lengths are <= 64, so the 17-bit
+          // sum cannot overflow past the saturated terminal element)
+          const uint32_t t_in = tn + ((1u << 10) | (cur.L << 15));
+          const uint32_t t_out_of = cur.out_code | (1u << 10) | (cur.Ls << 15);
+          const uint32_t t = !cur.inside ? t_pack(kExitEnd, 0, 0)
+                                         : (!cur.ok ? t_pack(kExitErr, 0, 0) : (cur.inreg ? t_in : t_out_of));
+          const uint32_t szb = cur.ok ? cur.szb : 255;
+          s_tab[row + k] = t;
+          if (SPLIT) s_sz[row8 + k] = (uint8_t)szb;
+          else szp[k >> 2] |= szb << (8 * (k & 3));
+          cur = nxt;
+          tn = tn_nxt;
+        }
       }
       };
       if (c0 + kChunk + 64 <= n) tabulate(std::true_type{});
