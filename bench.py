@@ -982,7 +982,7 @@ def main():
                 "kernel": "decode_indexed_kernel<32768>",  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),  # (HIP events; rocprof's average for this kernel agrees)
                 "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
-                "units_decoded_by_index_pass": sparse_units,  # (few, long elements: sparse_kernel.h)
+                "units_decoded_by_index_pass": sparse_units,  # (one literal / one period / few long elements: sparse_kernel.h)
                 "their_bytes_per_launch": int(sparse_bytes),   # ... not in `achieved`'s numerator
                 # every unit's bytes over all three kernels of a step (index pass + both decode launches)
                 "step_achieved": round(step_achieved, 2), "step_frac": round(step_achieved / HBM_PEAK_GBPS, 5),
