@@ -924,3 +924,114 @@ def test_sparse_units_decoder(hip, orc, torch_mod):
             else:
                 assert want_st == hip.INVALID_INPUT and int(ol[j]) == 0
     ctx.close()
+
+
+def _period_stream(lit, off, total, tail_form=2):
+    """A literal, then copies of ONE offset up to `total` output bytes (what encodeBlock makes of a period): copy2
+    elements of 64 bytes and a last shorter one (tail_form 1: as a copy1 when it fits that form)."""
+    body, out = bytearray(), bytearray(lit)
+    m = len(lit) - 1
+    if m < 60:
+        body.append(m << 2)
+    else:
+        ll = max((m.bit_length() + 7) // 8, 1)
+        body.extend(bytes([(59 + ll) << 2]) + m.to_bytes(ll, "little"))
+    body.extend(lit)
+    while len(out) < total:
+        ln = min(64, total - len(out))
+        if ln < 4:  # (no copy2 shorter than... as a literal that carries the period on: then the unit is no pure period)
+            body.append((ln - 1) << 2)
+            for _ in range(ln):
+                body.append(out[-off])
+                out.append(out[-off])
+            continue
+        if tail_form == 1 and ln <= 11 and off < 2048:
+            body.extend(bytes([((off >> 8) << 5) | ((ln - 4) << 2) | 1, off & 0xff]))
+        else:
+            body.extend(bytes([((ln - 1) << 2) | 2]) + off.to_bytes(2, "little"))
+        for _ in range(ln):
+            out.append(out[-off])
+    return bytes(body), bytes(out)
+
+
+@pytest.mark.gpu
+def test_units_the_index_pass_writes_itself(hip, orc, torch_mod):
+    """The two fast paths of the index pass (sparse_kernel.h: early_literal_unit, early_period_unit) and everything
+    that must NOT take them: one-literal units of every length class at every output alignment; periods of offset
+    1..4096 and beyond, with short and long first literals, totals that are no multiple of 16, unaligned outputs, a last
+    element in the other copy form, one record with another offset, a stream of more than 4 KiB -- each against the
+    oracle, with and without the CRC."""
+    torch = torch_mod
+    rng = random.Random(0xEA71)
+    units = []
+    for n in (1, 2, 15, 16, 17, 59, 60, 61, 255, 256, 257, 1023, 4096, 65535, 65536):  # one literal
+        data = rng.randbytes(n)
+        m = n - 1
+        hdr = bytes([m << 2]) if m < 60 else bytes([(59 + max((m.bit_length() + 7) // 8, 1)) << 2]) + m.to_bytes(
+            max((m.bit_length() + 7) // 8, 1), "little")
+        units.append((hdr + data, data))
+    for off, l0, total in ((1, 1, 65536), (1, 1, 65521), (2, 7, 4099), (3, 3, 65536), (10, 10, 65536), (10, 33, 65530),
+                           (64, 64, 65536), (255, 300, 65536), (1000, 1000, 30000), (2047, 2047, 65536),
+                           (2048, 2100, 65536), (4096, 4096, 65536), (4097, 4097, 65536), (5000, 6000, 65536),
+                           (7, 61, 100), (1, 1, 5), (16, 16, 48), (4096, 5000, 9000)):
+        lit = rng.randbytes(l0)
+        units.append(_period_stream(lit, off, total))
+        units.append(_period_stream(lit, off, total, tail_form=1))
+    # one record of another offset in the middle: not a period (the indexed decoder takes it)
+    b, p = _period_stream(rng.randbytes(40), 20, 65536)
+    k = 1 + 40 + 3 * 7
+    assert b[k] & 3 == 2
+    b2 = b[:k + 1] + (21).to_bytes(2, "little") + b[k + 3:]
+    st2, p2 = orc.decode_all_tags(b2, 65536)
+    assert st2 == 0
+    units.append((b2, p2))
+    # a stream of more than 4 KiB that is a period all the same (short copies): the indexed decoder's job
+    body, out = bytearray([3 << 2]) + bytearray(b"abcd"), bytearray(b"abcd")
+    while len(out) < 65536 - 8:
+        body.extend(bytes([((4 - 1) << 2) | 2, 4, 0]))
+        out.extend(out[-4:])
+    units.append((bytes(body), bytes(out)))
+    for b, p in units:
+        assert orc.decode_all_tags(b, len(p)) == (0, p)
+    nu = len(units)
+    in_off, out_off, pos, opos = [], [], 0, 0
+    for k, (b, p) in enumerate(units):
+        in_off.append(pos)
+        pos += len(b) + rng.randint(0, 7)
+        opos = (opos + 15) & ~15
+        if k % 2:
+            opos += rng.randint(1, 15)  # (an unaligned output: the period path declines, the literal path does not care)
+        out_off.append(opos)
+        opos += len(p) + rng.randint(0, 3)
+    stream = np.zeros(pos + 64, np.uint8)
+    for j, o in enumerate(in_off):
+        stream[o:o + len(units[j][0])] = np.frombuffer(units[j][0], np.uint8)
+    ctx = hip.Context(0)
+    d_stream = _dev(torch, stream)
+    d_in_off = _dev(torch, np.array(in_off, np.int64))
+    d_in_len = _dev(torch, np.array([len(u[0]) for u in units], np.int32))
+    d_out_off = _dev(torch, np.array(out_off, np.int64))
+    d_out_cap = _dev(torch, np.array([len(u[1]) for u in units], np.int32))
+    for with_crc in (False, True):
+        d_out_len = torch.zeros(nu, dtype=torch.int32, device="cuda")
+        d_status = torch.full((nu,), 77, dtype=torch.int32, device="cuda")
+        d_dec = torch.full((opos + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+        d_crc = torch.zeros(nu, dtype=torch.int32, device="cuda") if with_crc else None
+        before = ctx.kernel_ms(10)[1]
+        ctx.decode_blocks(d_stream, d_in_off, d_in_len, nu, d_dec, d_out_off, d_out_cap, d_out_len, d_status,
+                          unit=hip.UNIT_BODY, d_crc=d_crc)
+        ctx.sync()
+        assert ctx.kernel_ms(10)[1] - before >= 15 + 10  # (every one-literal unit, the aligned periods of offset <= 4096)
+        st = d_status.cpu().numpy()
+        ol = d_out_len.cpu().numpy()
+        got = d_dec.cpu().numpy()
+        prev_end = 0
+        for j, (b, p) in enumerate(units):
+            assert int(st[j]) == 0 and int(ol[j]) == len(p), (j, int(st[j]), int(ol[j]), len(p))
+            assert got[out_off[j]:out_off[j] + len(p)].tobytes() == p, (with_crc, j)
+            assert (got[prev_end:out_off[j]] == 0xA5).all(), j  # (nothing written between the units)
+            prev_end = out_off[j] + len(p)
+            if with_crc:
+                assert int(d_crc[j].item()) & 0xffffffff == orc.masked_crc(p), j
+        assert (got[prev_end:] == 0xA5).all()
+    ctx.close()
