@@ -52,13 +52,20 @@ constexpr uint32_t kD2Ring = 4096;
 constexpr uint32_t kElemCap = 1024;  // elements per 2 KiB step: the format's maximum (2 bytes each)
 constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles per pass (4 per lane)
 // The output window: the whole block (kMaxBlockLen), or a RING of the last kRingWin bytes (see the kernel).
-constexpr uint32_t kRingWin = 32768;
+// (Round 4: 16 KiB, FOUR workgroups a CU at 64 registers a lane, instead of 32 KiB and three at 80: the kernel is bound
+// by the instructions its resolver waves issue, and 24 of them a CU do a quarter more than 18 -- the sources a smaller ring
+// no longer holds are read back from the L2, which was measured to cost next to nothing here)
+#ifndef D2_RING_WIN
+#define D2_RING_WIN 16384
+#endif
+constexpr uint32_t kRingWin = D2_RING_WIN;
+constexpr uint32_t d2_wgs_per_cu(uint32_t win) { return win <= 16384 ? 4 : (win < kMaxBlockLen ? 3 : 1); }  // (by LDS)
 #ifndef D2_RING
 #define D2_RING 1  // (0: experiments, the whole-block instantiation only)
 #endif
 constexpr bool kD2RingFirst = D2_RING != 0;
 #ifndef D2_RING_CATCHUPS
-#define D2_RING_CATCHUPS 2
+#define D2_RING_CATCHUPS 32  // (html in a ring of 16 KiB: a catch-up flush every few steps is cheaper than the whole-block window)
 #endif
 constexpr uint32_t kRingCatchUps = D2_RING_CATCHUPS;  // wide steps (see the kernel) a unit may have in the ring
 // dynamic LDS of a launch: the window and 64 scratch dwords behind it, one per lane (no bank conflicts)
@@ -159,8 +166,8 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 
 // WIN = kMaxBlockLen: the window holds the whole unit, two workgroups per CU.
 // WIN = kRingWin: the window is a ring of the unit's last WIN output bytes -- out[x] lives at x & (WIN - 1)
-// -- so that THREE workgroups fit a CU (the kernel is bound by a block's chain of steps, and a CU hides
-// one block's chain behind the others': profiles/README.md).  Every step starts by writing the bytes that
+// -- so that FOUR workgroups fit a CU (16 KiB and 64 registers a lane; round 3: three, with 32 KiB and 80: the kernel
+// is bound by what its resolver waves issue, and a CU hides one block's chain behind the others': profiles/README.md).  Every step starts by writing the bytes that
 // became final one step ago to HBM; a copy whose source is older than what this step leaves of the ring
 // (ring_lo) reads it back from there -- those bytes were written at least a step earlier (far_lo, with a
 // wait for the stores in front of the barrier in between).  The ring is sound while the output of the step
@@ -175,7 +182,7 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // threads 256..511 take the rows the flush has just completed, their column registers live across the steps.
 // The framed stream (uncompressFramed, snappy.nim:231) then decodes on the ring kernel too.
 template <uint32_t WIN, bool RCRC = false>
-__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 * 3 + 3) / 4 : 1) void decode_indexed_kernel(Decode2Params prm) {
+__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 * d2_wgs_per_cu(WIN) + 3) / 4 : 1) void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
   static_assert(RING || !RCRC, "the whole-block instantiation checksums its window at the end");
   constexpr uint32_t kOutSink = WIN;
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
   // (the ring window is a static array: its LDS address is then a compile-time constant that folds into the
   // instructions' offset fields -- the dynamic array's base is added to every address with an instruction;
   // -2.5 % kernel time)
-  __shared__ __attribute__((aligned(16))) uint8_t s_static_window[RING ? out_alloc(kRingWin) : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_static_window[RING ? out_alloc(WIN) : 16];
   uint8_t* const s_out = RING ? s_static_window : s_dyn_window;
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[kD2Ring + 16];
   // pointer-doubling / start-mask scratch, one per resolver wave

@@ -654,7 +654,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       fprintf(stderr, "index verify: %d units with a mismatch\n", shown);
       (void)hipFree(d_rep);
     }
-    // The ring-window instantiation first, three workgroups per CU (with the CRC wanted: the variant that
+    // The ring-window instantiation first, four workgroups per CU (with the CRC wanted: the variant that
     // checksums the rows its flush completes); then the whole-block one over the units it passed on (a
     // workgroup of any other unit leaves at once).  kD2RingFirst == 0 / SNAPPY_HIP_NO_RING (debug builds):
     // whole-block only.

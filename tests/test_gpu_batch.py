@@ -655,7 +655,9 @@ def _ring_stream(rng, target, style):
     """One block's tag stream for the ring-window decoder (decode2_kernel.h): short literals and copies at
     a text-like ratio (so that three steps' output fits the ring), with copies whose sources lie further
     back than the ring holds, long literals, runs of same-offset copies, and -- style 'dense' -- stretches
-    of pure copies that make three steps' output outgrow the ring in the middle of the block."""
+    of pure copies that make two steps' output outgrow the ring in the middle of the block (the unit is passed on),
+    style 'mid' -- stretches at ~7 KiB of output a step: three steps outgrow a ring of 16 KiB, two do not (catch-up
+    flushes)."""
     out, body = bytearray(), bytearray()
 
     def lit(n):
@@ -683,6 +685,10 @@ def _ring_stream(rng, target, style):
         room = target - len(out)
         if style == "dense" and 20000 < len(out) < 45000:
             copy(rng.randint(1, min(len(out), 65535)), min(room, 64))
+        elif style == "mid" and 12000 < len(out) < 50000:  # ~7 KiB of output a step: three steps outgrow 16 KiB, two do not
+            copy(rng.randint(1, min(len(out), 65535)), min(room, rng.randint(12, 20)))
+            if rng.random() < 0.5:
+                lit(min(target - len(out), rng.randint(1, 3)) or 1) if len(out) < target else None
         elif r < 0.45:
             lit(min(room, rng.randint(1, 40)))
         elif r < 0.47:
@@ -698,13 +704,13 @@ def _ring_stream(rng, target, style):
                 copy(off, min(target - len(out), 64))
         else:
             far = rng.random() < 0.25
-            off = rng.randint(min(len(out), 30000), min(len(out), 65535)) if far else rng.randint(1, min(len(out), 3000))
+            off = rng.randint(min(len(out), 14000), min(len(out), 65535)) if far else rng.randint(1, min(len(out), 3000))
             copy(off, min(room, rng.randint(4, 40)))
     return bytes(body), bytes(out)
 
 
 def test_ring_window_decoder(hip, orc, torch_mod):
-    """the indexed decoder's two instantiations (ring of the last 32 KiB first, whole block for the units it
+    """the indexed decoder's two instantiations (ring of the last 16 KiB first, whole block for the units it
     passes on), without and with the CRC coming out of the decode kernels (the ring instantiation checksums
     the rows its flush completes): foreign streams whose copies reach behind the ring, wrap it, run across
     its end; outputs at unaligned addresses; output lengths of every residue mod 4 and mod 1024"""
@@ -712,7 +718,7 @@ def test_ring_window_decoder(hip, orc, torch_mod):
     rng = random.Random(99)
     units = []
     for i in range(240):
-        style = ("text", "biglit", "dense", "text")[i % 4]
+        style = ("text", "biglit", "dense", "mid")[i % 4]
         target = 65536 if i % 3 else rng.randint(33000, 65536)
         body, plain = _ring_stream(rng, target, style)
         units.append((body, plain))
