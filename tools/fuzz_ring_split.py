@@ -18,7 +18,7 @@ text = b"".join(open(os.path.join(ROOT, "tests", "golden", "data", f), "rb").rea
 def ring_case(rng, ctx):
     units = []
     for i in range(rng.randint(40, 160)):
-        style = rng.choice(["text", "biglit", "dense", "text"])
+        style = rng.choice(["text", "biglit", "dense", "mid"])
         units.append(_ring_stream(rng, rng.choice([65536, 65536, rng.randint(1, 65536)]), style))
     in_off, out_off, pos, opos = [], [], 0, 0
     reps = rng.randint(1, 8)
