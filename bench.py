@@ -22,7 +22,7 @@ sharded_compress: BASELINE configs[4] inside the same line -- a FIXED total (32 
           (a shared mapping all ranks register); strong_GBps = total bytes / slowest rank, and the stream's
           digest is compared with a single-GPU encoding of the same bytes.
 
-roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel<32768> (pass 2
+roofline : block decode is HBM-bound byte work.  Dominant kernel = decode_indexed_kernel<16384> (pass 2
           of the v2 decoder, ring-window instantiation; pass 1, index_units_kernel, and the whole-block
           instantiation's launch over the units the ring one passes on are reported beside it; `achieved` divides
           by the two decode launches' durations together, `traffic` is the ring kernel's).  achieved =
@@ -53,7 +53,10 @@ HBM_PEAK_GBPS = 8000.0
 BLOCK = 65536
 
 
-def measured_traffic(nb, only, kernels=("decode_indexed_kernel<32768>", "decode_indexed_kernel")):
+RING_KERNEL = "decode_indexed_kernel<16384>"  # (the ring-window instantiation: decode2_kernel.h, kRingWin)
+
+
+def measured_traffic(nb, only, kernels=(RING_KERNEL, "decode_indexed_kernel<32768>", "decode_indexed_kernel")):
     """(HBM bytes per launch of a kernel, note) from the PMC passes of tools/profile_bench.sh (FETCH_SIZE / WRITE_SIZE
     cannot be read inside this process: they need their own rocprofv3 passes).  The committed measurement is for
     the default workload only, and for ONE state of the kernel sources: the file carries their sha256
@@ -979,7 +982,7 @@ def main():
                 "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "traffic": measured_traffic(nb, args.only)[0],
                 "traffic_source": measured_traffic(nb, args.only)[1],  # (null traffic: why)
-                "kernel": "decode_indexed_kernel<32768>",  # (ring window; <65536> takes the units it passes on)
+                "kernel": RING_KERNEL,  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),  # (HIP events; rocprof's average for this kernel agrees)
                 "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
                 "units_decoded_by_index_pass": sparse_units,  # (one literal / one period / few long elements: sparse_kernel.h)

@@ -84,7 +84,7 @@ def test_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     (root / "include" / "snappy_hip.h").write_text("// abi\n")
     monkeypatch.setattr(bench, "ROOT", str(root))
     sha1 = build_id.csrc_sha256(str(root))
-    kern = {"kernels": {"decode_indexed_kernel<32768>": {"total_bytes": 7.0e9}}}
+    kern = {"kernels": {bench.RING_KERNEL: {"total_bytes": 7.0e9}}}
     (root / "profiles" / "r01_traffic.json").write_text(json.dumps(dict(kern, csrc_sha256=sha1)))
     v, why = bench.measured_traffic(65536, None)
     assert v == 7.0e9 and "r01_traffic.json" in why

@@ -5,9 +5,10 @@ import build_id
 out = sys.argv[1]
 def short(k):
     # the indexed decoder's two instantiations: ring window first, whole-block window for what it passes on
-    if "decode_indexed_kernel<32768u, true" in k or "decode_indexed_kernelILj32768ELb1" in k:
-        return "decode_indexed_kernel<32768,crc>"  # (the ring instantiation that checksums the rows it flushes)
-    for win in ("32768", "65536"):
+    for win in ("16384", "32768"):
+        if "decode_indexed_kernel<%su, true" % win in k or "decode_indexed_kernelILj%sELb1" % win in k:
+            return "decode_indexed_kernel<%s,crc>" % win  # (the ring instantiation that checksums the rows it flushes)
+    for win in ("16384", "32768", "65536"):
         if "decode_indexed_kernel<%s" % win in k or "decode_indexed_kernelILj%s" % win in k:
             return "decode_indexed_kernel<%s>" % win
     for name in ("decode_indexed_kernel", "index_units_kernel", "decode_units_kernel", "encode_blocks_kernel",
