@@ -59,6 +59,15 @@ constexpr uint32_t kGroup = 256;     // output bytes one resolver wave handles p
 #define D2_RING_WIN 16384
 #endif
 constexpr uint32_t kRingWin = D2_RING_WIN;
+// The checksumming ring instantiation (RCRC) serves decode_blocks' d_crc only when built with -DD2_FUSED_CRC=1 (a variant
+// library of the tests, tests/test_gpu_faults.py).  Shipped: crc32c_units_kernel over the decoded units -- with a ring of
+// 16 KiB at 64 registers the checksumming variant spills fifteen of them and costs the ring kernel +0.9 ms per 55 167 chunks,
+// the separate pass over their 3.6 GB 0.6 ms less than that and the CRC pass over the index pass's units it replaces
+// (framed stream 442 -> 474 GB/s; with the 32 KiB ring of round 3 the fused form was the faster one).
+#ifndef D2_FUSED_CRC
+#define D2_FUSED_CRC 0
+#endif
+constexpr bool kD2FusedCrc = D2_FUSED_CRC != 0;
 constexpr uint32_t d2_wgs_per_cu(uint32_t win) { return win <= 16384 ? 4 : (win < kMaxBlockLen ? 3 : 1); }  // (by LDS)
 #ifndef D2_RING
 #define D2_RING 1  // (0: experiments, the whole-block instantiation only)

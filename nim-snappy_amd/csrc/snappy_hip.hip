@@ -610,7 +610,7 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       ip.order = (const uint32_t*)d_perm;
       dp.order = (const uint32_t*)d_perm;
     }
-    if (d_crc && !dbg_env("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
+    if (d_crc && kD2FusedCrc && !dbg_env("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
       if ((st = ws_get(c, 14, n_units, &d_done))) return st;
       HIP_TRY(hipMemsetAsync(d_done, 0, n_units, s));
       dp.crc = d_crc;
@@ -661,10 +661,14 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     const bool ring_first = kD2RingFirst && !dbg_env("SNAPPY_HIP_NO_RING");
     if (ring_first) {
       LaunchTimer lt(c, s, 0);
-      if (dp.crc)  // (the CRC out of the ring's flush: the framed stream's chunks, snappy.nim:231)
-        LAUNCH((decode_indexed_kernel<kRingWin, true>), dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
-      else
-        LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
+      bool launched = false;
+      if constexpr (kD2FusedCrc) {
+        if (dp.crc) {  // (the CRC out of the ring's flush: the framed stream's chunks, snappy.nim:231)
+          LAUNCH((decode_indexed_kernel<kRingWin, true>), dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);
+          launched = true;
+        }
+      }
+      if (!launched) LAUNCH(decode_indexed_kernel<kRingWin>, dim3((uint32_t)n_units), dim3(kD2Threads), 0, s, dp);  // (static window)
     }
     if (ring_first) {  // the units it passed on, as a list
       void* d_pass;

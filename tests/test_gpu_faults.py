@@ -90,3 +90,24 @@ def test_parity_with_the_recovery_paths_forced(k):
     assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
     j0 = json.loads(q.stdout.strip().splitlines()[-1])
     assert j0["enc_equal"] and j0["dec_equal"] and j0["given_up"] == 0, j0
+
+
+@pytest.mark.gpu
+def test_checksumming_ring_instantiation_variant():
+    """decode_indexed_kernel<16384, true> -- the CRC out of the ring's flush -- is not what the shipped library uses for
+    decode_blocks' d_crc any more (decode2_kernel.h, D2_FUSED_CRC): a variant library built with it runs the tests that
+    compare the decoder's CRCs and bytes with the oracle's (ragged units, ring edges, a framed batch)."""
+    path = os.path.join(ROOT, "tools", "probes", "lib_fusedcrc.so")
+    src = os.path.join(ROOT, "nim-snappy_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    if not os.path.exists(path) or os.path.getmtime(path) < newest:
+        subprocess.run([os.path.join(ROOT, "tools", "mkvariant.sh"), "fusedcrc", "-DD2_FUSED_CRC=1"], check=True,
+                       capture_output=True, timeout=900)
+    env = dict(os.environ, SNAPPY_HIP_LIBRARY=path)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_decode_crc_ragged_units",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_ring_window_decoder",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_framed_batch_bit_exact",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_units_the_index_pass_writes_itself"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
