@@ -1032,7 +1032,7 @@ def main():
             line["config1_alice29"] = config1_alice29(hip)
             line["config_readme_files"] = config_readme_files(hip, corpus, ctx, dev)
             del d_packed, d_out
-            line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 8192))
+            line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 16384))  # (16 waves of workgroups of the ring kernel)
             line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy(), ctx, dev)
         print(json.dumps(line), flush=True)
     ctx.close()
