@@ -413,6 +413,7 @@ def per_class_rates(hip, corpus, ctx, dev, nb):
         assert bool(torch.equal(d_out, d_in)), cls
         u = nb * BLOCK
         out[cls] = {
+            "blocks": nb,
             "decompress_GBps": round(u / t / 1e9, 1),
             "decode_kernel_ms": round(dec_ms, 3), "passed_on_units_kernel_ms": round(dec2_ms, 3),
             # units of few, long elements are decoded inside the index pass (sparse_kernel.h): their bytes are not the
