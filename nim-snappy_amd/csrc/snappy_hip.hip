@@ -1828,7 +1828,10 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   bool done = false;
   int cur = 0;
   for (int look = 0; look < kMaxLooks && !done; look++) {
-    for (int r = 0; r < (look == 0 ? kRoundsFirst : kRoundsLater); r++) {
+    // (a look at the chain is a dozen pointer-jump launches over every node and a synchronisation: 0.5 ms for the 2 M
+    // segments of a 1 GiB buffer, as much as two and a half rounds -- big streams walk eight rounds between later looks)
+    const int rounds_later = nseg > (1u << 20) ? 2 * kRoundsLater : kRoundsLater;
+    for (int r = 0; r < (look == 0 ? kRoundsFirst : rounds_later); r++) {
       LaunchTimer lt(c, s, 7);
       sp.first = look == 0 && r == 0;
       LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
