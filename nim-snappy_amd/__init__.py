@@ -29,8 +29,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnappy_hip.so")
 # (test hook: a variant build of the SAME sources -- fault injection, A/B experiments -- in place of the shipped library;
 # tests/test_gpu_faults.py, tools/ab.sh)
-if os.environ.get("SNAPPY_HIP_LIBRARY"):
+LIB_OVERRIDDEN = bool(os.environ.get("SNAPPY_HIP_LIBRARY"))
+if LIB_OVERRIDDEN:
+    import sys as _sys
     LIB_PATH = os.environ["SNAPPY_HIP_LIBRARY"]
+    print("nim-snappy_amd: SNAPPY_HIP_LIBRARY is set -- loading %s instead of the shipped library" % LIB_PATH,
+          file=_sys.stderr)
 
 OK, BUFFER_TOO_SMALL, INVALID_INPUT, CRC_MISMATCH, UNKNOWN_CHUNK = range(5)
 DEVICE_ERROR = 100

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
       cscan += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cscan, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
       const uint32_t call = readlane(cscan, 63);
       if (wave == 0 && lane == 0) s_cnt[buf] = (call & 0xffffu) + (call >> 16);  // (<= kElemCap by the format)
-      bool bad = false;
+      bool bad = false, far_off = false;
 #pragma unroll 1
       for (uint32_t trip = 0; trip < kFeTrips; trip++) {
       const uint32_t vw = wave * kFeTrips + trip;  // which 256 bytes of the step
@@ -725,6 +725,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
         {
           const bool badA = hasA && !litA && offA - 1 >= dstA, badB = hasB && !litB && offB - 1 >= dstB;  // decoder.nim:112
           bad = bad || badA || badB;
+          // (0xffff in the list means "literal", and 65 535 is a legal copy offset -- of ONE element: a copy at output
+          // position 65 535 of a full block, decoder.nim:112.  A unit that holds it goes to the one-pass kernel.)
+          far_off = far_off || (hasA && !litA && !badA && offA == 0xffffu) || (hasB && !litB && !badB && offB == 0xffffu);
           uint32_t* const sink32 = reinterpret_cast<uint32_t*>(sink16);
           *(hasA ? el + slotA : sink32) = ((litA || badA) ? 0xffffu : offA) | (dstA << 16);  // (list value of a literal: 0xffff)
           *(hasB ? el + slotB : sink32) = ((litB || badB) ? 0xffffu : offB) | (dstB << 16);
@@ -839,7 +842,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 *
         if (hd + body + lane < eL) s_out[wa(ed + hd + body + lane)] = in0[es + hd + body + lane];
       }
       }  // trips
-      if (ballot(bad) && lane == 0) s_err = 1;
+      if (ballot(bad) && lane == 0) atomicOr(&s_err, 1u);
+      if (__builtin_expect(ballot(far_off) != 0, 0) && lane == 0) atomicOr(&s_err, 4u);
       __builtin_amdgcn_s_setprio(0);
       acc_b += 1;
     }

@@ -623,11 +623,18 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
       }
     };
 #ifndef IDX_NO_EARLY_LIT
-    if (first_n == 1 && first_out == op) {  // the first element writes every byte: a literal (a copy cannot be first)
+    // The first element writes every byte.  It must BE a literal: this pass validates no copy offsets, and a unit
+    // whose one element is a copy (`01 01`, `fe 01 00`: decoder.nim:112 rejects them, op <= offset - 1) would
+    // otherwise be "copied" from the bytes behind its stream.  Such a unit falls through to kOk, and the indexed
+    // decoder's offset check gives the reference's verdict.
+    if (first_n == 1 && first_out == op && (in0[0] & 3) == 0) {
       const uint32_t hi6 = (uint32_t)in0[0] >> 2;
-      early_literal_unit(in0 + 1 + (hi6 >= 60 ? hi6 - 59 : 0), gptr, op);
-      count_early();
-      return finish(kDoneEarly, op);
+      const uint32_t lenlen = hi6 >= 60 ? hi6 - 59 : 0;
+      if (1 + lenlen + op == n) {
+        early_literal_unit(in0 + 1 + lenlen, gptr, op);
+        count_early();
+        return finish(kDoneEarly, op);
+      }
     }
 #endif
     if (n <= 4096) {

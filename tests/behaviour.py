@@ -53,6 +53,25 @@ def check_bad_data(be):
     assert st == INVALID_INPUT
 
 
+def check_lone_copy_units(be):
+    """a unit that is one copy and nothing else: invalidInput (decoder.nim:112), as raw buffer and as tag stream"""
+    for raw in cases.LONE_COPY_UNITS:
+        assert be.decode(raw) == b"", raw
+        st, out = be.uncompress(raw, raw[0])
+        assert st == INVALID_INPUT, raw
+        for cap in (raw[0], 64, 65536):
+            st, out = be.decode_all_tags(raw[1:], cap)
+            assert st == INVALID_INPUT, (raw, cap)
+
+
+def check_encoder_reproduces_golden_rawsnappy(be):
+    """The one file of encoder output the reference holds (tests/test_snappy.nim:71-83 decodes it): re-encoding its
+    plaintext gives the file back byte for byte (9 871 bytes; a 14 KB block, where encoder.nim:36-37's fixed shift and
+    libsnappy's size-dependent one pick the same slots)."""
+    raw = golden_file("Mark.Twain-Tom.Sawyer.txt.rawsnappy")
+    assert be.encode(be.decode(raw)) == raw
+
+
 def check_compresses(be):
     """tests/test_snappy.nim:150-154"""
     assert len(be.encode(bytes(1024))) < 512

@@ -35,6 +35,17 @@ BAD_DATA = [
     b"\x11\x00\x00\xfc\xff\xff\xff\xff",              # 4-byte literal length wraps to 0
 ]
 
+# Not from the reference's list -- units whose ONLY element is a copy (decoder.nim:112: op <= offset - 1 with op = 0 is
+# invalidInput).  The decoder's "one element writes every byte" shortcut must not take them for a literal.
+LONE_COPY_UNITS = [
+    b"\x04\x01\x01",                  # copy1, length 4, offset 1
+    b"\x0b\x1d\x01",                  # copy1, length 11, offset 1
+    b"\x40\xfe\x01\x00",              # copy2, length 64, offset 1
+    b"\x01\x02\x01\x00",              # copy2, length 1
+    b"\x04\x0f\x01\x00\x00\x00",      # copy4, length 4, offset 1
+    b"\x40\xff\x40\x00\x00\x00",      # copy4, length 64, offset 64
+]
+
 RANDOM1 = bytes([
     0, 0, 0, 0, 1, 0, 0, 0, 2, 0, 0, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5, 0, 0, 1, 1,
     0, 0, 1, 2, 0, 0, 2, 1, 0, 0, 2, 2, 0, 0, 0, 6, 0, 0, 3, 1, 0, 0, 0, 7, 0,

@@ -29,6 +29,8 @@ def test_reference_block_suite(hip, orc, vectors):
     bh.check_literal61_quirk(hip)
     bh.check_caller_buffer_rules(hip, orc)
     bh.check_golden_rawsnappy(hip, vectors)
+    bh.check_encoder_reproduces_golden_rawsnappy(hip)
+    bh.check_lone_copy_units(hip)
     for w in cases.WITNESSES:
         assert bh.check_round_trip(hip, w) == orc.encode(w)
 
@@ -126,6 +128,50 @@ def test_raw_multi_block_streams(hip, orc):
     # 4. the same kinds, damaged: identical verdicts
     for bad in (orc.encode(text[:200000])[:-3], s2[:-1], s3[:40000], s3[:-101] + bytes([0xfc])):
         assert hip.uncompress(bad, 400000)[0] == orc.uncompress(bad, 400000)[0] != bh.OK
+
+
+def test_input_longer_than_the_format_allows(hip):
+    """snappy.nim:41-42: len > 2^32 - 1 is invalidInput -- decided before the input is touched"""
+    import ctypes
+    w = ctypes.c_size_t(77)
+    out = ctypes.create_string_buffer(64)
+    for n in (1 << 32, (1 << 32) + 5, 1 << 40):
+        assert hip.lib.snappy_hip_compress(None, n, out, 64, ctypes.byref(w)) == bh.INVALID_INPUT
+    assert hip.lib.snappy_hip_max_compressed_len(0xFFFFFFFF) == 32 + 0xFFFFFFFF + 0xFFFFFFFF // 6
+
+
+def test_copy_offset_65535(hip, orc):
+    """65 535 is a legal copy offset for exactly one element: a copy at output position 65 535 of a full block
+    (decoder.nim:112 wants offset <= op).  The indexed decoder's element list keeps 16-bit offsets: such a unit must
+    still give the reference's bytes -- many short elements (the ring decoder's units), a short stream that is no
+    period, copy2 and copy4 forms, and the same element one position early (offset > op: invalidInput)."""
+    rng = random.Random(65535)
+    # (a) 1 093 literals of 60 bytes, then the copy
+    plain = rng.randbytes(65535)
+    lits = b"".join(_literal(plain[i:i + 60]) for i in range(0, 65535, 60))
+    # (b) one literal and a stretch of copies with changing offsets: stream < 4 KiB, > 832 elements, not a period
+    out_b = bytearray(rng.randbytes(100))
+    body_b = bytearray(_literal(bytes(out_b)))
+    k = 0
+    while len(out_b) < 65535:
+        ln = min(64, 65535 - len(out_b))
+        off = 100 - (k % 7)
+        body_b += bytes([((ln - 1) << 2) | 2]) + off.to_bytes(2, "little")
+        for _ in range(ln):
+            out_b.append(out_b[-off])
+        k += 1
+    for body, pl in ((lits, plain), (bytes(body_b), bytes(out_b))):
+        for tail in (bytes([0x02, 0xff, 0xff]), bytes([0x03, 0xff, 0xff, 0x00, 0x00])):
+            want = pl + pl[:1]
+            assert orc.decode_all_tags(body + tail, 65536) == (0, want)
+            assert hip.decode_all_tags(body + tail, 65536) == (0, want)
+            assert hip.decode(_varint(65536) + body + tail) == want
+        # one byte less in front of it: op = 65 534 < offset
+        short = _literal(pl[:59]) + body[61:] if body is lits else None
+        if short is not None:
+            bad = short + bytes([0x02, 0xff, 0xff])
+            assert orc.decode_all_tags(bad, 65536)[0] == bh.INVALID_INPUT
+            assert hip.decode_all_tags(bad, 65536)[0] == bh.INVALID_INPUT
 
 
 def test_random_strings(hip, orc):
