@@ -5,7 +5,9 @@
 // snappy/encoder.nim:385-426.  Output is byte-identical to the reference encoder: the greedy
 // parse is a strictly sequential algorithm, so one wave EMULATES it exactly for one block:
 //
-//   * the uint16[16384] hash table lives in LDS (32 KiB), zeroed per block like the reference;
+//   * the uint16[16384] hash table lives in LDS (32 KiB), zeroed per block like the reference -- for the four blocks per CU
+//     that the LDS holds; since round 5 every workgroup carries a SECOND wave whose block keeps its table in global
+//     memory (32 KiB that stay in the XCD's L2; plain 16-bit loads and stores, see "the table elsewhere" below);
 //   * the reference's probe sequence after a literal start is data-independent (skip starts at
 //     32, step = skip>>5): 64 lanes take the next 64 probe positions of that sequence, hash
 //     them, read the table, write their own position, and detect same-slot collisions inside
@@ -16,8 +18,8 @@
 //   * the copy-loop probe at `ip` right after a copy (encoder.nim:371-380) rides along as lane 0
 //     of the next round, so one round finds either "copy again" or the next literal + copy;
 //   * match extension compares 256 bytes per step across the wave (ballot + ctz);
-//   * elements are emitted through a 4 KiB LDS staging buffer and flushed with wide stores;
-//   * the bytes around the scan position live in a 2.3 KiB LDS window (refilled with 16-byte
+//   * elements are emitted through a 2 KiB LDS staging buffer and flushed with wide stores;
+//   * the bytes around the scan position live in a 1.5 KiB LDS window (refilled with 16-byte
 //     loads when the scan leaves it), so a round's only trip to HBM/L2 is the one that cannot be
 //     avoided: the candidates, which may lie anywhere earlier in the block.  A candidate is
 //     fetched 16 bytes wide, so matches of up to 16 bytes are measured from registers.
@@ -44,10 +46,26 @@
 namespace snappy_hip {
 
 constexpr uint32_t kSeqLen = 320;  // probe-sequence entries (offset passes 65536 at ~250)
-constexpr uint32_t kObSize = 4096; // staging bytes
-constexpr uint32_t kObFlushAt = 3000;  // drain() flushes above this fill; one of its steps adds <= 1 027 bytes
+// LDS per workgroup: the table (32 KiB + a sink slot per lane), per wave staging + window + 36 bytes, and the second wave's
+// scratch (2 KiB): 40 104 bytes -- four workgroups a CU (LDS is handed out in pieces of 1 280 bytes: 4 x 40 960 is all of
+// it), two waves each.
+#ifndef ENC_OB   // (-DENC_OB / ENC_WIN / ENC_WAVES: A/B experiments, tools/mkvariant.sh)
+#define ENC_OB 1024
+#endif
+#ifndef ENC_WIN
+#define ENC_WIN 1280
+#endif
+#ifndef ENC_WAVES
+#define ENC_WAVES 2
+#endif
+constexpr uint32_t kObSize = ENC_OB; // staging bytes
+constexpr uint32_t kObLitMax = kObSize / 4;  // a literal up to this length goes through the staging buffer
+constexpr uint32_t kObFlushAt = kObSize - kObLitMax - 3 - 3 * 64 - 128;  // drain() flushes above this fill; one of its steps adds <= kObLitMax + 3 bytes
 constexpr uint32_t kObCap = kObSize + 3 * 64 + 16;
-constexpr uint32_t kWinSize = 2304;  // bytes of input around the scan position kept in LDS
+constexpr uint32_t kWinSize = ENC_WIN;  // bytes of input around the scan position kept in LDS
+constexpr uint32_t kEncWaves = ENC_WAVES;  // waves per workgroup: wave 0's table is the LDS one, wave 1's lies in global memory
+constexpr uint32_t kEncScratchBits = 10;   // wave 1's scratch for finding the lanes of a round that share a table slot
+constexpr uint32_t kEncScratch = 1u << kEncScratchBits;  // (16-bit entries: 2 KiB)
 
 struct EncodeParams {
   const uint8_t* in;
@@ -62,30 +80,52 @@ struct EncodeParams {
   const uint32_t* seq_off;  // probe sequence: offset of probe j from the scan start
   const uint32_t* seq_step; // ... and its step (skip >> 5)
   unsigned long long* stats;  // DEBUG: per-section cycle counters (nullptr = off)
-  const uint32_t* order;      // workgroup i takes block order[i] (nullptr: block i; crc_pack_kernels.h)
+  const uint32_t* order;      // the i-th block taken is order[i] (nullptr: block i; crc_pack_kernels.h)
+  uint32_t* queue;            // [0] how many blocks have been taken (zeroed before the launch)
+  uint16_t* gtables;          // one 32 KiB table per workgroup for its second wave (nullptr: no second waves)
+  uint32_t g_per4;            // of every four workgroups of an XCD, this many run their second wave (0..4)
+  uint32_t dbg;               // DEBUG builds only
 };
 
 __device__ __forceinline__ uint32_t snappy_hash(uint32_t u, uint32_t mask) {
   return ((u * 0x1e35a7bdu) >> (32 - kMaxTableBits)) & mask;  // encoder.nim:36-37
 }
 
-__global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
-  __shared__ __attribute__((aligned(16))) uint8_t s_ob[kObCap];
+// One block, one wave.  GT = false: the table is s_table (LDS).  GT = true, "the table elsewhere": the table is gtab, 32 KiB
+// of global memory that only this wave touches -- plain 16-bit stores and loads that go to the L2 (sc1: past the CU's
+// vector cache).  A wave's vector memory operations execute in order, so "read the slot, write my position, read it back"
+// is ONE trip: the first read sees the table as it was, the second who wrote last.  Lanes that share a slot find each other
+// through it (a lane that lost writes once more, then each of two reads the other; three and more go through a loop over
+// registers) -- no assumption about which lane of a store instruction wins.  Everything else is the same procedure.
+// (the LDS pointers carry their address space: left generic, half of the accesses through them come out as flat_
+// instructions, which a wave's ds_ instructions are not ordered against)
+typedef __attribute__((address_space(3))) uint8_t enc_lds8;
+typedef __attribute__((address_space(3))) uint16_t enc_lds16;
+typedef __attribute__((address_space(3))) uint32_t enc_lds32;
+typedef uint32_t enc_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) enc_v4 enc_lds128;
+template <bool GT>
+__device__ __forceinline__ void encode_one_block(const EncodeParams& prm, const uint64_t blk, enc_lds16* const s_table,
+                                                 uint16_t* const gtab, enc_lds16* const s_gx, enc_lds8* const s_ob,
+                                                 enc_lds8* const s_win, enc_lds32* const s_cold, enc_lds32* const s_walk_p) {
   // (north_star's layout -- the whole block staged in LDS next to the table, one block per CU -- was built and
   // measured in round 2: bit-exact, 3.8x slower; profiles/README.md)
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWinSize + 32];
   constexpr uint32_t kWin = kWinSize;
-  __shared__ uint32_t s_cold[8];             // the rarely pending output items (see below)
-#ifndef ENC_NO_CMPST_WALK
-  __shared__ uint32_t s_walk;                // the lane the chain stands at (walked by one ds_cmpst)
-#endif
-  __shared__ uint16_t s_seq_off[kSeqLen];   // saturated at 65535 (such a probe is never valid)
-  __shared__ uint16_t s_seq_step[kSeqLen];
+#define s_walk (*s_walk_p)
 
   const uint32_t lane = lane_id();
-  if (blockIdx.x >= prm.n_blocks) return;
-  const uint64_t blk = prm.order ? prm.order[blockIdx.x] : blockIdx.x;
+  // the table: loads by index, stores by the lanes that have something to store
+  auto T_ld = [&](uint32_t idx) -> uint32_t {
+    if constexpr (GT) return __hip_atomic_load(gtab + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_ushort sc1
+    else return s_table[idx];
+  };
+  auto T_st = [&](bool pred, uint32_t idx, uint32_t val) {
+    if constexpr (GT) {
+      if (pred) gtab[idx] = (uint16_t)val;
+    } else {
+      s_table[pred ? idx : kMaxTableSize + lane] = (uint16_t)val;  // (the others: their sink slot, no branch)
+    }
+  };
 
   const uint64_t in_pos = blk * (uint64_t)prm.block_len;
   const uint8_t* in = prm.in + in_pos;
@@ -124,7 +164,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     wave_fence();
     for (uint32_t i = lane; i < kWin / 16; i += 64) {
       const uint32_t q = wq + 16 * i;
-      if (q < q_end) *reinterpret_cast<uint4*>(s_win + 16 * i) = *reinterpret_cast<const uint4*>(g0 + q);
+      if (q < q_end) *reinterpret_cast<enc_lds128*>(s_win + 16 * i) = *reinterpret_cast<const enc_v4*>(g0 + q);
     }
     wend = wq + kWin < q_end ? wq + kWin : q_end;
     wave_fence();
@@ -146,7 +186,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
   // LDS, behind one flag in a register -- the parse loop is short of scalar registers (every spilled one is a
   // v_readlane / v_writelane on the round's chain of instructions)
   struct ColdU32 {
-    volatile uint32_t* p;
+    volatile enc_lds32* p;
     __device__ __forceinline__ operator uint32_t() const { return readfirst(*p); }
     __device__ __forceinline__ ColdU32& operator=(uint32_t v) {
       if (lane_id() == 0) *p = v;
@@ -208,11 +248,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       c_lit2_from = readlane(cw, 4), c_lit2_len = readlane(cw, 5);
     }
     for (;;) {
-      if (want_flush || ofill > kObFlushAt) {  // (a step below adds at most 1 027 bytes)
+      if (want_flush || ofill > kObFlushAt) {  // (a step below adds at most kObLitMax + 3 bytes)
         wave_fence();
         for (uint32_t i = lane * 4; i < ofill; i += 256) {
           if (i + 4 <= ofill) {
-            st32u(gout + gpos + i, *reinterpret_cast<const uint32_t*>(s_ob + i));
+            st32u(gout + gpos + i, *reinterpret_cast<const enc_lds32*>(s_ob + i));
           } else {
             for (uint32_t k = i; k < ofill; k++) gout[gpos + k] = s_ob[k];
           }
@@ -228,7 +268,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
       if (c_lit_len) {  // emitLiteral, encoder.nim:44-73: input[from ..< from+len], 1 <= len <= 65536
         const uint32_t from = c_lit_from, len = c_lit_len;
-        if (len > 1024 && ofill) {  // a long literal goes from HBM to HBM, behind what is waiting
+        if (len > kObLitMax && ofill) {  // a long literal goes from HBM to HBM, behind what is waiting
           want_flush = true;
           continue;
         }
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint32_t w = m < 60 ? 1 : (m < 256 ? 2 : 3);
         const uint32_t t0 = m < 60 ? (m << 2) : (m < 256 ? (60u << 2) : (61u << 2));
         const uint32_t tag = t0 | ((m & 255) << 8) | ((m >> 8) << 16);
-        if (len <= 1024) {
+        if (len <= kObLitMax) {
           if (lane < w) s_ob[ofill + lane] = (uint8_t)(tag >> (8 * lane));
           ofill += w;
           if (len <= 64 && in_window(from, len)) {  // the common case: straight from the window
@@ -324,12 +364,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     uint32_t table_size = 1u << 8;
     while (table_size < kMaxTableSize && table_size < n) table_size <<= 1;
     mask = table_size - 1;
-    for (uint32_t i = lane * 8; i < table_size; i += 64 * 8)
-      *reinterpret_cast<uint4*>(&s_table[i]) = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lane; i < kSeqLen; i += 64) {
-      const uint32_t o = prm.seq_off[i], st = prm.seq_step[i];
-      s_seq_off[i] = (uint16_t)(o < 65535 ? o : 65535);
-      s_seq_step[i] = (uint16_t)(st < 65535 ? st : 65535);
+    for (uint32_t i = lane * 8; i < table_size; i += 64 * 8) {
+      if constexpr (GT) *reinterpret_cast<uint4*>(&gtab[i]) = make_uint4(0, 0, 0, 0);
+      else *reinterpret_cast<enc_lds128*>(&s_table[i]) = enc_v4{0, 0, 0, 0};
     }
     wave_fence();
     fill_window(0);
@@ -415,7 +452,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       uint32_t d, pd1, pd2, pd3;
       {
         const uint32_t qa = p + shift - wq;
-        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+        const enc_lds32* w32 = reinterpret_cast<const enc_lds32*>(s_win + (qa & ~3u));
         const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
         const uint32_t sh8 = (qa & 3) * 8;
         d = __funnelshift_r(r0, r1, sh8);
@@ -426,9 +463,14 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       tick(0);
       const uint32_t h = snappy_hash(d, mask);
       const uint32_t sh16 = (h & 1) * 16;
-      const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_table[h & ~1u];
-      uint32_t old;
-      {  // the table in one trip (see the general round)
+      const uint32_t taddr = GT ? 0u : (uint32_t)(uintptr_t)&s_table[h & ~1u];
+      uint32_t old, cand, dep = 64;
+      bool inround = false;
+      // (GT) my slot of the scratch, and what I put there: 0x8000 | the hash bits the slot number leaves out | my lane
+      const uint32_t xsh = (h & 1) * 16;
+      const uint32_t xaddr = GT ? (uint32_t)(uintptr_t)&s_gx[h & (kEncScratch - 2)] : 0u;
+      const uint32_t xval = 0x8000u | ((h >> kEncScratchBits) << 6) | lane;
+      if constexpr (!GT) {  // the table in one trip (see the general round)
         uint32_t ret;
         wave_fence();
         asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
@@ -436,23 +478,63 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
                      : "v"(taddr), "v"(0xffffu << sh16), "v"((p & 0xffffu) << sh16)
                      : "memory");
         old = (ret >> sh16) & 0xffffu;
+        inround = old >= base;
+        cand = old;
+        dep = inround ? old - base : 64;
+      } else {
+        // The table elsewhere.  ONE scattered load reads the slots as they are; nothing is written before the round knows
+        // which lanes stay inserted (one scattered store at its end) -- a CU's vector memory pipeline takes ~140 cycles for
+        // a load and ~220 for a store of 64 scattered lanes (tools/probes/gtab_probe.hip), and with eight waves a CU that
+        // pipeline is what the rounds wait for.  The lanes of the round that share a slot find each other in LDS instead:
+        // a scratch of kEncScratch 16-bit entries indexed by the hash's low bits, through which every lane exchanges
+        // (ds_mskor_rtn_b32, lanes on one address served in ascending order -- checked, as for the LDS table) its lane
+        // and the remaining hash bits for what the lane before it on that entry put there: the same bits = the nearest
+        // earlier lane on my table slot; other bits = a lane of another slot in between (two per round): those few lanes
+        // are looked up with ballots.  Every lane clears its entry again.
+        old = T_ld(h);
+        uint32_t ret;
+        wave_fence();
+        asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\tds_write_b16 %4, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ret)
+                     : "v"(xaddr), "v"(0xffffu << xsh), "v"(xval << xsh), "v"(xaddr + (h & 1) * 2), "v"(0u)
+                     : "memory");
+        const uint32_t prev = (ret >> xsh) & 0xffffu;
+        const bool has = (prev & 0x8000u) != 0;
+        const bool same = has && ((prev ^ xval) & 0x7fc0u) == 0;
+        if (__builtin_expect(ballot(has && (prev & 63u) >= lane) != 0 || ENC_ORDER_FAULT(), 0)) {  // not served in ascending order
+          c_bail_order++;
+          break;  // (nothing has been written to the table)
+        }
+        dep = same ? (prev & 63u) : 64u;
+        uint64_t amb = ballot(has && !same);
+        while (amb) {  // (a lane of another slot sits between me and a possible earlier lane of mine)
+          const uint32_t j = ctz64(amb);
+          const uint32_t hj = readlane(h, j);
+          const uint64_t g = ballot(h == hj);
+          const uint64_t below = g & ((1ull << lane) - 1);
+          if (h == hj && below) dep = 63 - (uint32_t)__builtin_clzll(below);
+          amb &= ~g;
+        }
+        inround = dep < 64;
+        cand = inround ? base + dep : old;
       }
-      const bool inround = old >= base;
       const uint64_t conf = ballot(inround);  // lanes whose candidate is another lane of the round
       // puts the slots back to what the first-served lanes saw (the round is then done by the general form)
       auto undo_table = [&]() {
-        wave_fence();
-        asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"((inround ? 0u : 0xffffu) << sh16), "v"((inround ? 0u : old) << sh16)
-                     : "memory");
-        wave_fence();
+        if constexpr (!GT) {
+          wave_fence();
+          asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"((inround ? 0u : 0xffffu) << sh16), "v"((inround ? 0u : old) << sh16)
+                       : "memory");
+          wave_fence();
+        }  // (GT: nothing has been written)
       };
-      if (__builtin_expect(ballot(inround && old - base >= lane) != 0 || ENC_ORDER_FAULT(), 0)) {  // not served in ascending order
-        undo_table();
-        c_bail_order++;
-        break;
+      if constexpr (!GT) {
+        if (__builtin_expect(ballot(inround && old - base >= lane) != 0 || ENC_ORDER_FAULT(), 0)) {  // not served in ascending order
+          undo_table();
+          c_bail_order++;
+          break;
+        }
       }
-      const uint32_t cand = old;
-      const uint32_t dep = inround ? old - base : 64;
       uint4 cv;
       __builtin_memcpy(&cv, in + cand, 16);
       tick(1);
@@ -597,13 +679,36 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         break;
       }
       c_fast++;
-      {  // the table as the inserted lanes leave it (see the general round)
+      if constexpr (!GT) {  // the table as the inserted lanes leave it (see the general round)
         const bool firstm = old < base;
         const uint32_t mk = (firstm || in_s) ? 0xffffu : 0u;
         const uint32_t dv = in_s ? (p & 0xffffu) : (firstm ? old : 0u);
         wave_fence();
         asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"(mk << sh16), "v"(dv << sh16) : "memory");
         wave_fence();
+      } else {
+        // the table elsewhere: of the inserted lanes on one slot the last one writes its position.  The inserted lanes go
+        // through the scratch once more; who is on an entry last is that lane -- unless the entry is shared with another
+        // slot's lane or the order of service was not ascending: those lanes are settled with ballots.
+        uint32_t fin = xval;
+        if (in_s) {
+          asm volatile("ds_mskor_b32 %1, %2, %3\n\tds_read_u16 %0, %4\n\tds_write_b16 %4, %5\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(fin)
+                       : "v"(xaddr), "v"(0xffffu << xsh), "v"(xval << xsh), "v"(xaddr + (h & 1) * 2), "v"(0u)
+                       : "memory");
+        }
+        bool writer = in_s && fin == xval;
+        // (someone else is last on my entry: a later lane of my slot -- fine, it writes --, or not: look)
+        const bool inject = ENC_ORDER_FAULT();  // (tests: every inserted lane is looked up)
+        uint64_t amb = ballot(in_s && ((fin != xval && (((fin ^ xval) & 0x7fc0u) != 0 || (fin & 63u) < lane)) || inject));
+        while (amb) {
+          const uint32_t j = ctz64(amb);
+          const uint32_t hj = readlane(h, j);
+          const uint64_t g = ballot(in_s && h == hj);
+          if (in_s && h == hj) writer = lane == 63 - (uint32_t)__builtin_clzll(g);
+          amb &= ~g;
+        }
+        if (writer) gtab[h] = (uint16_t)p;
       }
       {  // hand the elements over
         const uint32_t mlast = 63 - (uint32_t)__builtin_clzll(MS);
@@ -673,7 +778,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         p = base + lane;
         valid = p <= ip_limit && (has0 || lane > 0);
         const uint32_t qa = valid ? (p + shift - wq) : 0;
-        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s_win + (qa & ~3u));
+        const enc_lds32* w32 = reinterpret_cast<const enc_lds32*>(s_win + (qa & ~3u));
         const uint32_t r0 = w32[0], r1 = w32[1], r2 = w32[2], r3 = w32[3], r4 = w32[4];
         const uint32_t sh8 = (qa & 3) * 8;
         d = __funnelshift_r(r0, r1, sh8);
@@ -684,9 +789,10 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         // a long scan, far ahead of the window: straight from memory
         const uint32_t si = idx0 + lane;
         p = s0;
-        if (si < kSeqLen) {
-          p = s0 + s_seq_off[si];
-          valid = p + s_seq_step[si] <= ip_limit;  // encoder.nim:318-321
+        if (si < kSeqLen) {  // (the probe sequence, from global memory: these rounds are rare and far apart)
+          const uint32_t so = prm.seq_off[si], st = prm.seq_step[si];
+          p = s0 + (so < 65535 ? so : 65535);  // saturated (such a probe is never valid)
+          valid = p + (st < 65535 ? st : 65535) <= ip_limit;  // encoder.nim:318-321
         }
         if (valid) d = ld32u(in + p);
       }
@@ -702,7 +808,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     }
     const uint32_t h = snappy_hash(d, mask);
     // (a lane without a position works on its private sink slot instead of being branched around)
-    const uint32_t ti = valid ? h : tsink;
+    const uint32_t ti = (GT || valid) ? h : tsink;  // (GT: a lane without a position reads slot h(0) and stores nothing)
     uint4 cv;
     uint64_t grp = 1ull << lane;  // lanes of this round that share my slot
     bool any_conflict = false;
@@ -716,13 +822,13 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     // be an EARLIER lane's (any other order of service shows some lane a later one's); if not, the slots go back
     // to what the first-served lanes saw and the plain form below does the round.
 #ifndef ENC_NO_ATOMIC_TABLE
-    bool atab = fresh && has0 && base + 96 <= ip_limit;
+    bool atab = !GT && fresh && has0 && base + 96 <= ip_limit;
 #else
     bool atab = false;
 #endif
     const uint32_t sh16 = (h & 1) * 16;
-    const uint32_t taddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&s_table[h & ~1u];
-    if (atab) {
+    const uint32_t taddr = GT ? 0u : (uint32_t)(uintptr_t)&s_table[h & ~1u];
+    if (!GT && atab) {
       uint32_t ret;
       wave_fence();
       asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
@@ -743,14 +849,14 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       }
     }
     if (!atab) {
-      old = s_table[ti];
+      old = T_ld(ti);
       cand = old;
       {
         wave_fence();
-        s_table[ti] = (uint16_t)p;
+        T_st(valid, h, p);
         wave_fence();
-        const uint32_t chk = s_table[ti];
-        const bool lost = chk != (p & 0xffffu);  // another lane of the round has my slot, and wrote last
+        const uint32_t chk = T_ld(ti);
+        const bool lost = valid && chk != (p & 0xffffu);  // another lane of the round has my slot, and wrote last
         uint64_t losers = ballot(lost);
 
         // candidate as the sequential loop would see it if every earlier lane was inserted: the
@@ -761,9 +867,9 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
           // now each of the two reads the other's position (its lane: positions are consecutive).
           // A lane that loses again is one of three or more on a slot; those go through the loop.
           wave_fence();
-          s_table[lost ? h : tsink] = (uint16_t)p;
+          T_st(lost, h, p);
           wave_fence();
-          const uint32_t chk2 = s_table[ti];
+          const uint32_t chk2 = T_ld(ti);
           const bool lost2 = lost && chk2 != (p & 0xffffu);
           const uint32_t partner = ((lost ? chk : chk2) - base) & 0xffffu;
           if (valid && (lost || chk2 != (p & 0xffffu))) {
@@ -1015,7 +1121,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       tick(6);  // chain: what was inserted, what is covered (and the general chain)
       // ---- leave the table as the lanes the sequential loop touched would have left it ---------
       wave_fence();
-      if (atab) {
+      if (!GT && atab) {
         // (the same service in ascending lane order, checked above for these very lanes and addresses: the
         // first-served lane of a slot -- it saw what the table held -- restores that unless it stays inserted,
         // every later lane that stays inserted overwrites: the last inserted lane of a slot writes last)
@@ -1024,11 +1130,11 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
         const uint32_t dv = in_s ? (p & 0xffffu) : (firstm ? old : 0u);  // (nothing is OR-ed in where nothing is masked out)
         asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(taddr), "v"(mk << sh16), "v"(dv << sh16) : "memory");
       } else if (!any_conflict) {  // every lane has a slot of its own: the others take their writes back
-        s_table[(valid && !in_s) ? h : tsink] = (uint16_t)old;
+        T_st(valid && !in_s, h, old);
       } else {              // of the lanes on one slot the last one that was touched wrote last
         const uint64_t gs = grp & ballot(in_s);
         const uint32_t top = gs ? 63 - (uint32_t)__builtin_clzll(gs) : 64;
-        s_table[(valid && (gs == 0 || top == lane)) ? h : tsink] = (uint16_t)(gs == 0 ? old : p);
+        T_st(valid && (gs == 0 || top == lane), h, gs == 0 ? old : p);
       }
       wave_fence();
       if (MS) {  // hand the elements over
@@ -1075,7 +1181,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     // leave the table as the sequential loop would
     if (mm || confl) {
       wave_fence();
-      s_table[(valid && lane > m_eff) ? h : tsink] = (uint16_t)old;  // never executed there
+      T_st(valid && lane > m_eff, h, old);  // never executed there
     }
     if (any_conflict) {
       wave_fence();
@@ -1083,7 +1189,7 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
       const uint64_t later = lane >= 63 ? 0 : (grp >> (lane + 1));
       const uint32_t span = m_eff > lane ? m_eff - lane : 0;  // lanes in (lane, m_eff]
       const uint64_t later_in = span >= 64 ? later : (later & ((1ull << span) - 1));
-      s_table[(valid && lane <= m_eff && later_in == 0) ? h : tsink] = (uint16_t)p;
+      T_st(valid && lane <= m_eff && later_in == 0, h, p);
     }
     wave_fence();
     if (!mm) {
@@ -1163,6 +1269,62 @@ __global__ __launch_bounds__(64) void encode_blocks_kernel(EncodeParams prm) {
     unit_len = frame_len + 4;
   }
   if (lane == 0) prm.sizes[blk] = unit_len;
+#undef s_walk
+}
+
+// Persistent workgroups of two waves: each wave takes the next block of the launch order until none is left (one counter;
+// a returning atomic per block, ~1 us against the ~50-1 500 us a block takes).  Wave 0 works with the table in LDS; wave 1
+// -- in g_per4 of every four workgroups of an XCD -- with its table in global memory (encode_one_block<true>): two more
+// waves per CU for every such workgroup, whose 32 KiB tables (g_per4 x 256 KiB per CU quad... at most 4 MiB per XCD at
+// g_per4 = 4) have to stay in the XCD's 4 MiB L2 beside the input: g_per4 is the host's choice (snappy_hip.hip).
+__global__ __launch_bounds__(64 * kEncWaves) void encode_blocks_kernel(EncodeParams prm) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
+  __shared__ __attribute__((aligned(16))) uint8_t s_ob[kEncWaves][kObCap];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kEncWaves][kWinSize + 32];
+  __shared__ uint32_t s_cold[kEncWaves][8];  // the rarely pending output items
+  __shared__ uint32_t s_walk[kEncWaves];     // the lane the chain stands at (walked by one ds_cmpst)
+  __shared__ __attribute__((aligned(16))) uint16_t s_gx[kEncWaves > 1 ? kEncScratch : 2];  // the second wave's scratch: all zero between its uses
+  const uint32_t wave = readfirst(threadIdx.x >> 6);
+  // (blocks b and b + 8 share an XCD: the second waves are spread evenly over the XCDs)
+  if (wave == 1 && (prm.gtables == nullptr || ((blockIdx.x >> 3) & 3) >= (prm.g_per4 & 7))) return;
+  if (SNAPPY_DBG(prm) && wave == 0 && (prm.g_per4 & 0x100)) return;  // DEBUG: the second waves alone
+  uint16_t* const gtab = wave == 1 ? prm.gtables + (size_t)blockIdx.x * kMaxTableSize : nullptr;
+  if (kEncWaves > 1 && wave == 1) {
+    for (uint32_t i = lane_id(); i < kEncScratch / 2; i += 64) reinterpret_cast<uint32_t*>(s_gx)[i] = 0;
+    wave_fence();
+  }
+  const unsigned long long queue_s = ((unsigned long long)readfirst((uint32_t)((uintptr_t)prm.queue >> 32)) << 32) |
+                                     readfirst((uint32_t)(uintptr_t)prm.queue);  // (in scalar registers)
+  for (;;) {
+    // Every lane executes the same code: lane 0's returning add under a hand-set EXEC.  NOT `if (lane == 0) k = atomicAdd(..)`
+    // and a broadcast: a loop is each lane's own loop to the compiler, and it turned that form into lanes 1..63 spinning
+    // on the broadcast value in a loop of their own with lane 0 masked off -- which never ends.
+    // (written out: the compiler's form of an add whose operand differs by lane is a loop over the 64 lanes)
+    uint32_t took;
+    {
+      unsigned long long save;
+      asm volatile(
+          "s_mov_b64 %[save], exec\n\t"
+          "s_mov_b64 exec, 1\n\t"
+          "global_atomic_add %[r], %[zero], %[one], %[ptr] sc0\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "s_mov_b64 exec, %[save]"
+          : [r] "=&v"(took), [save] "=&s"(save)
+          : [zero] "v"(0u), [one] "v"(1u), [ptr] "s"(queue_s)
+          : "memory");
+    }
+    const uint32_t k = readfirst(took);
+    if (k >= prm.n_blocks) break;
+    const uint64_t blk = prm.order ? prm.order[k] : k;
+    if (SNAPPY_DBG(prm) && lane_id() == 0) atomicAdd(prm.queue + 1 + wave, 1u);  // DEBUG: who took how many
+    if (wave == 0) {
+      encode_one_block<false>(prm, blk, (enc_lds16*)s_table, nullptr, nullptr, (enc_lds8*)s_ob[0], (enc_lds8*)s_win[0], (enc_lds32*)s_cold[0],
+                              (enc_lds32*)&s_walk[0]);
+    } else if constexpr (kEncWaves > 1) {
+      encode_one_block<true>(prm, blk, nullptr, gtab, (enc_lds16*)s_gx, (enc_lds8*)s_ob[kEncWaves - 1], (enc_lds8*)s_win[kEncWaves - 1],
+                             (enc_lds32*)s_cold[kEncWaves - 1], (enc_lds32*)&s_walk[kEncWaves - 1]);
+    }
+  }
 }
 
 }  // namespace snappy_hip

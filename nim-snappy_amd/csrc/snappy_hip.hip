@@ -133,6 +133,9 @@ struct snappy_hip_ctx {
   hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_busy[4] = {false, false, false, false};
   bool stage_failed = false;       // the ring could not be allocated: copies go the runtime's pageable way
+  int n_cus = 256;                 // compute units of the device (the encoder's persistent grid: four workgroups each)
+  uint64_t enc_g_min_blocks = 0;   // ... from this many blocks a batch on (0: twice the resident workgroups)
+  uint32_t enc_g_per4 = 4;         // of four encoder workgroups, how many run a second wave with its table in global memory
   bool launch_order = true;        // batches of >= 512 units are launched in sorted order (snappy_hip_ctx_launch_order)
   bool timing = false;
   struct Timed {
@@ -244,6 +247,16 @@ extern "C" const char* snappy_hip_last_error(void) { return g_last_error.c_str()
 
 namespace {
 int ctx_init(snappy_hip_ctx* c) {
+  {
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (cus > 0) c->n_cus = cus;
+    if (const char* e = getenv("SNAPPY_HIP_ENC_GWAVES")) {  // tuning knob (include/snappy_hip.h): "g" or "g,min_blocks"
+      const int v = atoi(e);
+      c->enc_g_per4 = (uint32_t)(v < 0 ? 0 : (v > 4 ? 4 : v));
+      if (const char* comma = strchr(e, ',')) c->enc_g_min_blocks = strtoull(comma + 1, nullptr, 10);
+    }
+  }
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   {  // (least priority: the main stream's small launches are not to queue behind the side stream's workgroups)
     int least = 0, greatest = 0;
@@ -489,9 +502,32 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
     p.stats = d_estats;
   }
   {
+    // Persistent workgroups (encode_kernel.h): four fit a CU (LDS), each takes blocks from one queue until none is left.
+    // Their second waves -- tables in global memory, 32 KiB each, which must stay in the XCD's L2 -- run in g_per4 of every
+    // four workgroups; a batch that does not fill the GPU's LDS-table waves starts none.
+    const uint32_t resident = 4u * (uint32_t)c->n_cus;
+    const uint32_t grid = nb < resident ? (uint32_t)nb : resident;
+    uint32_t g_per4 = nb >= (c->enc_g_min_blocks ? c->enc_g_min_blocks : 2 * (uint64_t)resident) ? c->enc_g_per4 : 0;
+    void* qp;
+    int st = ws_get(c, 21, 64 + (g_per4 ? (size_t)grid * kMaxTableSize * 2 : 0), &qp);
+    if (st) return st;
+    HIP_TRY(hipMemsetAsync(qp, 0, 64, s));
+    p.queue = (uint32_t*)qp;
+    p.gtables = g_per4 ? (uint16_t*)((uint8_t*)qp + 64) : nullptr;
+    p.g_per4 = g_per4;
+    if (dbg_env("SNAPPY_HIP_ENC_DBG")) {  // DEBUG: bit 8 of g_per4 = the second waves alone; counters of who took how many
+      p.dbg = 1;
+      p.g_per4 |= (uint32_t)atoi(dbg_env("SNAPPY_HIP_ENC_DBG")) & 0x100u;
+    }
     LaunchTimer lt(c, s, 1);
-    LAUNCH(encode_blocks_kernel, dim3((uint32_t)nb), dim3(64),
+    LAUNCH(encode_blocks_kernel, dim3(grid), dim3(64 * kEncWaves),
            dbg_env("SNAPPY_HIP_ENC_LDS") ? atoi(dbg_env("SNAPPY_HIP_ENC_LDS")) : 0 /* DEBUG: fewer blocks per CU */, s, p);
+  }
+  if (dbg_env("SNAPPY_HIP_ENC_DBG")) {
+    uint32_t q[4];
+    HIP_TRY(hipMemcpyAsync(q, p.queue, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    fprintf(stderr, "ENC blocks taken by table-in-LDS waves %u, by table-in-memory waves %u (g_per4 %u)\n", q[1], q[2], p.g_per4);
   }
   if (d_estats) {
     unsigned long long h[16];

@@ -68,7 +68,9 @@ def _variant(k):
 @pytest.mark.parametrize("k", [1, 7])
 def test_parity_with_the_recovery_paths_forced(k):
     lib = _variant(k)
-    env = dict(os.environ, SNAPPY_HIP_LIBRARY=lib)
+    # (SNAPPY_HIP_ENC_GWAVES=4,1: the encoder's second waves -- tables in global memory, a path of their own with order
+    # checks of their own -- run on every batch, not only on those that fill the GPU)
+    env = dict(os.environ, SNAPPY_HIP_LIBRARY=lib, SNAPPY_HIP_ENC_GWAVES="4,1")
     # the encoder's byte equality with the oracle (every data file, the structured fuzz, the corpus sample) and the
     # decoder's round trips, with every k-th check failing / every k-th waited-for turn given up on
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
@@ -90,6 +92,26 @@ def test_parity_with_the_recovery_paths_forced(k):
     assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
     j0 = json.loads(q.stdout.strip().splitlines()[-1])
     assert j0["enc_equal"] and j0["dec_equal"] and j0["given_up"] == 0, j0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gwaves", ["4,1", "0"])
+def test_encoder_with_and_without_its_second_waves(gwaves):
+    """The shipped library, the encoder's second waves (encode_kernel.h, encode_one_block<true>: the table in global
+    memory, same-slot lanes found through an LDS scratch) on EVERY batch however small -- or on none: the encoder's byte
+    equality with the oracle either way (blocks are handed out dynamically: both kinds of wave encode every kind of block)."""
+    env = dict(os.environ, SNAPPY_HIP_ENC_GWAVES=gwaves)
+    env.pop("SNAPPY_HIP_LIBRARY", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_data_files_bit_exact",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_every_small_length",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_match_runs_into_block_end",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_copies_longer_than_a_round_at_every_lane",
+                        os.path.join(ROOT, "tests", "test_gpu_parity.py") + "::test_synthetic_patterns_bit_exact",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_structured_fuzz_round_trip",
+                        os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_corpus_sample_bit_exact"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
