@@ -83,6 +83,21 @@ def measured_traffic(nb, only, kernels=(RING_KERNEL, "decode_indexed_kernel<3276
                   "tools/profile_bench.sh" % (mine[:16], stale, "other sources" if stale else "nothing"))
 
 
+STEP_KERNELS = ("index_units_kernel", RING_KERNEL, "decode_indexed_kernel<65536>")  # the kernels of one decode step
+
+
+def measured_step_traffic(nb, only):
+    """HBM bytes of one whole decode step (index pass + ring launch + the passed-on units' launch) from the same
+    profile as measured_traffic, or None"""
+    total = 0.0
+    for k in STEP_KERNELS:
+        v, _ = measured_traffic(nb, only, (k,))
+        if v is None:
+            return None
+        total += v
+    return total
+
+
 def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_all):
     """Oracle (CPU port of the reference) on the first n_sample blocks, one thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -162,17 +177,91 @@ def cpu_baseline(corpus, d_in, d_packed, offsets, sizes, n_sample, budget_s, nb_
         "threads_value": all_d,
         "compress_threads_value": all_e,
         "threads_sweep_decompress_compress_GBps": {str(k): list(v) for k, v in sweep.items()},
+        # the sweep's spread (the box's CPU quota makes the legs noisy: quote the range, not only the best)
+        "threads_value_min_max": [min(v[0] for v in sweep.values()), all_d],
+        "compress_threads_value_min_max": [min(v[1] for v in sweep.values()), all_e],
         "threads64_value": t64_d,
         "compress_threads64_value": t64_e,
         "host_cpus": ncpu,
     }
 
 
+class AbiCaller:
+    """The reference's in-memory API through a C ABI on PREALLOCATED numpy buffers, the way a Nim caller holds its
+    seqs (snappy.nim:66-82,118-128): no Python-side allocation or copy inside the timed call.  `lib` is the HIP
+    library (snappy_hip_*) or the oracle (sor_*): same five-argument shape."""
+
+    def __init__(self, lib, prefix, src, cap_raw, cap_framed):
+        import ctypes
+        self.ct = ctypes
+        self.lib, self.prefix = lib, prefix
+        self.src = np.frombuffer(src, dtype=np.uint8)
+        self.raw = np.empty(cap_raw, dtype=np.uint8)
+        self.fr = np.empty(cap_framed, dtype=np.uint8)
+        self.back = np.empty(max(len(src), 1), dtype=np.uint8)
+        self.w, self.r = ctypes.c_size_t(), ctypes.c_size_t()
+        self.raw_len = self.fr_len = 0
+
+    def _p(self, a):  # (an input pointer: both libraries declare it c_char_p)
+        return self.ct.cast(self.ct.c_void_p(a.ctypes.data), self.ct.c_char_p)
+
+    def _o(self, a):  # (an output pointer)
+        return self.ct.c_void_p(a.ctypes.data)
+
+    def encode(self):
+        st = getattr(self.lib, self.prefix + "compress")(self._p(self.src), self.src.size, self._o(self.raw), self.raw.size,
+                                                         self.ct.byref(self.w))
+        assert st == 0, st
+        self.raw_len = self.w.value
+
+    def decode(self):
+        st = getattr(self.lib, self.prefix + "uncompress")(self._p(self.raw), self.raw_len, self._o(self.back), self.src.size,
+                                                           self.ct.byref(self.w))
+        assert st == 0 and self.w.value == self.src.size, (st, self.w.value)
+
+    def encode_framed(self):
+        st = getattr(self.lib, self.prefix + "compress_framed")(self._p(self.src), self.src.size, self._o(self.fr), self.fr.size,
+                                                                self.ct.byref(self.w))
+        assert st == 0, st
+        self.fr_len = self.w.value
+
+    def decode_framed(self):
+        st = getattr(self.lib, self.prefix + "uncompress_framed")(self._p(self.fr), self.fr_len, self._o(self.back),
+                                                                  self.src.size, 1, 1, self.ct.byref(self.r), self.ct.byref(self.w))
+        assert st == 0 and self.w.value == self.src.size, (st, self.w.value)
+
+    def check_against(self, other):
+        """same bytes out of both libraries, and the source back"""
+        for leg in ("encode", "encode_framed"):
+            getattr(self, leg)()
+            getattr(other, leg)()
+        assert self.raw_len == other.raw_len and np.array_equal(self.raw[:self.raw_len], other.raw[:other.raw_len])
+        assert self.fr_len == other.fr_len and np.array_equal(self.fr[:self.fr_len], other.fr[:other.fr_len])
+        for c in (self, other):
+            c.back[:] = 0
+            c.decode()
+            assert np.array_equal(c.back[:c.src.size], c.src)
+            c.back[:] = 0
+            c.decode_framed()
+            assert np.array_equal(c.back[:c.src.size], c.src)
+
+
+def _callers(hip, orc, src):
+    """(HIP, oracle) C-ABI callers over the same source bytes"""
+    cap_raw = hip.max_compressed_len(len(src))
+    cap_fr = hip.max_compressed_len_framed(len(src))
+    h = AbiCaller(hip.lib, "snappy_hip_", src, cap_raw, cap_fr)
+    o = AbiCaller(orc.lib, "sor_", src, cap_raw, cap_fr)
+    h.check_against(o)
+    return h, o
+
+
 def config1_alice29(hip):
     """BASELINE configs[0]: tests/data/alice29.txt single-buffer encode / decode, timed the way the
     reference's harness does (tests/benchmark.nim:20-23,93-104: mean over 100 calls, ms per call) --
     the oracle on one host core (the Nim inMemory path cannot be built here), and the HIP library's
-    host-buffer calls (PCIe and launch latency included: 3 blocks cannot fill a GPU)."""
+    host-buffer calls (PCIe and launch latency included: 3 blocks cannot fill a GPU).  Both through their C ABI on
+    preallocated buffers (AbiCaller): what is timed is the library call, not Python's buffer handling."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as orc
     with open(os.path.join(ROOT, "tests", "golden", "data", "alice29.txt"), "rb") as fh:
@@ -183,19 +272,16 @@ def config1_alice29(hip):
         t0 = time.perf_counter()
         for _ in range(reps):
             f()
-        return (time.perf_counter() - t0) / reps * 1e3
+        return round((time.perf_counter() - t0) / reps * 1e3, 4)
 
-    enc = orc.encode(src)
-    fr = orc.encode_framed(src)
-    assert hip.encode(src) == enc and hip.encode_framed(src) == fr and hip.decode(enc) == src
+    h, o = _callers(hip, orc, src)
     return {
         "file": "alice29.txt", "bytes": len(src), "calls": 100, "unit": "ms per call (encode / decode)",
-        "oracle_inMemory_raw": [round(mean_ms(lambda: orc.encode(src)), 4), round(mean_ms(lambda: orc.decode(enc)), 4)],
-        "oracle_inMemory_framed": [round(mean_ms(lambda: orc.encode_framed(src)), 4),
-                                   round(mean_ms(lambda: orc.decode_framed(fr)), 4)],
-        "hip_host_api_raw": [round(mean_ms(lambda: hip.encode(src)), 4), round(mean_ms(lambda: hip.decode(enc)), 4)],
-        "hip_host_api_framed": [round(mean_ms(lambda: hip.encode_framed(src)), 4),
-                                round(mean_ms(lambda: hip.decode_framed(fr)), 4)],
+        "through": "the C ABI on preallocated buffers (both libraries)",
+        "oracle_inMemory_raw": [mean_ms(o.encode), mean_ms(o.decode)],
+        "oracle_inMemory_framed": [mean_ms(o.encode_framed), mean_ms(o.decode_framed)],
+        "hip_host_api_raw": [mean_ms(h.encode), mean_ms(h.decode)],
+        "hip_host_api_framed": [mean_ms(h.encode_framed), mean_ms(h.decode_framed)],
         "reference_README_x86_64": {"raw": [0.334, 0.186], "framed": [0.382, 0.251]},
     }
 
@@ -241,14 +327,13 @@ def config_readme_files(hip, corpus, ctx, dev, calls=30):
     for name, (ref_raw, ref_fr) in README_TABLE.items():
         with open(os.path.join(ROOT, "tests", "golden", "data", name), "rb") as fh:
             src = fh.read()
-        enc, fr = orc.encode(src), orc.encode_framed(src)
-        assert hip.encode(src) == enc and hip.encode_framed(src) == fr and hip.decode(enc) == src and hip.decode_framed(fr) == src
+        h, o = _callers(hip, orc, src)  # (also checks: same bytes out of both, the source back)
         rows.append({
             "file": name, "bytes": len(src),
-            "oracle_raw": [mean_ms(lambda: orc.encode(src), calls), mean_ms(lambda: orc.decode(enc), calls)],
-            "hip_host_raw": [mean_ms(lambda: hip.encode(src), calls), mean_ms(lambda: hip.decode(enc), calls)],
-            "oracle_framed": [mean_ms(lambda: orc.encode_framed(src), calls), mean_ms(lambda: orc.decode_framed(fr), calls)],
-            "hip_host_framed": [mean_ms(lambda: hip.encode_framed(src), calls), mean_ms(lambda: hip.decode_framed(fr), calls)],
+            "oracle_raw": [mean_ms(o.encode, calls), mean_ms(o.decode, calls)],
+            "hip_host_raw": [mean_ms(h.encode, calls), mean_ms(h.decode, calls)],
+            "oracle_framed": [mean_ms(o.encode_framed, calls), mean_ms(o.decode_framed, calls)],
+            "hip_host_framed": [mean_ms(h.encode_framed, calls), mean_ms(h.decode_framed, calls)],
             "reference_README_inMemory": {"raw": list(ref_raw), "framed": list(ref_fr)},
         })
     # the 38.9 MB single buffer
@@ -256,8 +341,8 @@ def config_readme_files(hip, corpus, ctx, dev, calls=30):
     nb = -(-n // BLOCK)
     d_src = corpus.make_blocks_torch(torch, 0, nb, dev).reshape(-1)[:n].contiguous()
     src = d_src.cpu().numpy().tobytes()
-    enc, fr = hip.encode(src), hip.encode_framed(src)
-    assert hip.decode(enc) == src and hip.decode_framed(fr) == src
+    h, o = _callers(hip, orc, src)
+    enc, fr = h.raw[:h.raw_len].tobytes(), h.fr[:h.fr_len].tobytes()
     d_fr = torch.empty(hip.max_compressed_len_framed(n), dtype=torch.uint8, device=dev)
     d_back = torch.empty(n, dtype=torch.uint8, device=dev)
     flen = ctx.compress_framed(d_src, n, d_fr, d_fr.numel())
@@ -267,10 +352,11 @@ def config_readme_files(hip, corpus, ctx, dev, calls=30):
     state = {
         "bytes": n, "data": "synthetic (corpus mix; the reference's state file is not in its tree)",
         "compressed_bytes": {"raw": len(enc), "framed": len(fr)},
-        "oracle_raw": [mean_ms(lambda: orc.encode(src), 3), mean_ms(lambda: orc.decode(enc), 3)],
-        "oracle_framed": [mean_ms(lambda: orc.encode_framed(src), 3), mean_ms(lambda: orc.decode_framed(fr), 3)],
-        "hip_host_raw_p50": [p50_ms(lambda: hip.encode(src)), p50_ms(lambda: hip.decode(enc))],
-        "hip_host_framed_p50": [p50_ms(lambda: hip.encode_framed(src)), p50_ms(lambda: hip.decode_framed(fr))],
+        "oracle_raw": [mean_ms(o.encode, 3), mean_ms(o.decode, 3)],
+        "oracle_framed": [mean_ms(o.encode_framed, 3), mean_ms(o.decode_framed, 3)],
+        "hip_host_raw_p50": [p50_ms(h.encode), p50_ms(h.decode)],
+        "hip_host_framed_p50": [p50_ms(h.encode_framed), p50_ms(h.decode_framed)],
+        "hip_host_raw_GBps": None, "hip_host_framed_GBps": None,  # (filled in below)
         # input and output resident in HBM (snappy_hip_compress_framed_d / _uncompress_framed_d / _uncompress_d)
         "hip_device_framed_p50": [p50_ms(lambda: ctx.compress_framed(d_src, n, d_fr, d_fr.numel())),
                                   p50_ms(lambda: ctx.uncompress_framed(d_fr, flen, d_back, n))],
@@ -278,8 +364,10 @@ def config_readme_files(hip, corpus, ctx, dev, calls=30):
         "reference_README_inMemory": {"raw": list(README_STATE["raw"]), "framed": list(README_STATE["framed"]),
                                       "note": "another buffer (a real beacon state), x86_64, one thread, 50 calls"},
     }
-    return {"what": "README.md:97-125 / tests/benchmark.nim on this box: ms per call, [encode, decode]", "calls": calls,
-            "files": rows, "state_38_9MB": state}
+    for k in ("raw", "framed"):
+        state["hip_host_%s_GBps" % k] = [round(n / (t * 1e-3) / 1e9, 2) for t in state["hip_host_%s_p50" % k]]
+    return {"what": "README.md:97-125 / tests/benchmark.nim on this box: ms per call, [encode, decode]; both libraries "
+                    "through their C ABI on preallocated buffers", "calls": calls, "files": rows, "state_38_9MB": state}
 
 
 def host_api_rates(hip, src_np, ctx=None, dev=None):
@@ -795,6 +883,11 @@ def main():
     dev = torch.device("cuda", local)
 
     hip = importlib.import_module("nim-snappy_amd")  # raises if the HIP library is missing
+    if hip.LIB_OVERRIDDEN and not os.environ.get("BENCH_ALLOW_LIBRARY_OVERRIDE"):
+        # (SNAPPY_HIP_LIBRARY is a test / A-B hook: a fault-injection build must not be measured by accident)
+        print("bench: SNAPPY_HIP_LIBRARY is set (%s); set BENCH_ALLOW_LIBRARY_OVERRIDE=1 to measure a variant library"
+              % hip.LIB_PATH, file=sys.stderr)
+        sys.exit(2)
     import corpus
     import shard
     ctx = hip.Context(local)
@@ -841,20 +934,27 @@ def main():
     d_fstream = torch.empty(fcap, dtype=torch.uint8, device=dev)
     flen = ctx.compress_framed(d_in, nb * BLOCK, d_fstream, fcap)  # warm
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    flen = ctx.compress_framed(d_in, nb * BLOCK, d_fstream, fcap)
-    t_fenc = time.perf_counter() - t0
+    fenc_ts = []
+    for _ in range(max(1, min(3, args.steps))):
+        t0 = time.perf_counter()
+        flen = ctx.compress_framed(d_in, nb * BLOCK, d_fstream, fcap)  # (returns the length: synchronous)
+        fenc_ts.append(time.perf_counter() - t0)
+    t_fenc = sum(fenc_ts) / len(fenc_ts)
     d_fout = torch.empty(nb * BLOCK, dtype=torch.uint8, device=dev)
     st_f = ctx.uncompress_framed(d_fstream, flen, d_fout, nb * BLOCK)  # warm
     assert st_f == (0, flen, nb * BLOCK), st_f
     ctx.timing(True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    st_f = ctx.uncompress_framed(d_fstream, flen, d_fout, nb * BLOCK)
-    t_fdec = time.perf_counter() - t0
+    fdec_ts = []  # every call timed on its own (a call returns the verdict: it is synchronous): mean and min over --steps
+    for _ in range(max(1, args.steps)):
+        t0 = time.perf_counter()
+        st_f = ctx.uncompress_framed(d_fstream, flen, d_fout, nb * BLOCK)
+        fdec_ts.append(time.perf_counter() - t0)
+        assert st_f == (0, flen, nb * BLOCK), st_f
+    t_fdec = sum(fdec_ts) / len(fdec_ts)
     walk_ms, _ = ctx.kernel_ms(6)
     ctx.timing(False)
-    assert st_f == (0, flen, nb * BLOCK) and bool(torch.equal(d_fout, d_in)), "framed round trip differs"
+    assert bool(torch.equal(d_fout, d_in)), "framed round trip differs"
     del d_fstream, d_fout
 
     # ---- the timed hot path: block decompress --------------------------------------------------------
@@ -905,6 +1005,7 @@ def main():
     assert bool(torch.equal(d_out, d_in)), "decoded bytes differ from the corpus"
 
     t_fdec = shard.max_over_ranks(dist if world > 1 else None, t_fdec, dev)
+    t_fdec_min = shard.max_over_ranks(dist if world > 1 else None, min(fdec_ts), dev)
 
     # ---- measured copy bandwidth of this box: the second roofline denominator of SURVEY 8(d) -------
     torch.cuda.synchronize()
@@ -923,20 +1024,27 @@ def main():
         total_blocks = max(world, want_blocks)
         free_b, _ = torch.cuda.mem_get_info(dev)
         room = _host_room_bytes()
-        while total_blocks > world:
-            per_rank = (total_blocks + world - 1) // world * BLOCK
-            gpu_need = per_rank * 1.6 + min(65536, per_rank // BLOCK) * hip.SLOT_STRIDE + (4 << 30)
-            if os.environ.get("BENCH_SHARE_DEVICE"):
-                gpu_need *= world
-            host_need = 0.6 * total_blocks * BLOCK * 2.5 + (2 << 30)
-            if gpu_need <= free_b and host_need <= room:
-                break
-            total_blocks //= 2
-        if world > 1:  # every rank must use the same total: the smallest anyone can afford
-            t = torch.tensor([total_blocks], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        # The total is FIXED (configs[4] is strong scaling): a box that cannot hold it does not get a smaller one
+        # silently -- the leg is refused, with the reason in the line (and on stderr); `--shard-gib` names another total.
+        per_rank = (total_blocks + world - 1) // world * BLOCK
+        gpu_need = per_rank * 1.6 + min(65536, per_rank // BLOCK) * hip.SLOT_STRIDE + (4 << 30)
+        if os.environ.get("BENCH_SHARE_DEVICE"):
+            gpu_need *= world
+        host_need = 0.6 * total_blocks * BLOCK * 2.5 + (2 << 30)
+        fits = 1 if (gpu_need <= free_b and host_need <= room) else 0
+        if world > 1:  # (every rank must come to the same decision)
+            t = torch.tensor([fits], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            total_blocks = int(t.item())
-        sharded = sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, total_blocks, want_blocks)
+            fits = int(t.item())
+        if fits:
+            sharded = sharded_compress_leg(hip, ctx, corpus, shard, rank, world, dev, backend, total_blocks, want_blocks)
+        else:
+            why = ("%.1f GiB in %d shard(s) needs %.0f GB of device memory per rank (free: %.0f) and %.0f GB of host memory "
+                   "for the one host buffer, /dev/shm included (room: %.0f): not run; --shard-gib names a smaller fixed total"
+                   % (total_blocks * BLOCK / 2**30, world, gpu_need / 1e9, free_b / 1e9, host_need / 1e9, room / 1e9))
+            if rank == 0:
+                print("bench: sharded_compress refused: " + why, file=sys.stderr)
+            sharded = {"refused": why, "total_blocks": total_blocks, "n_shards": world}
 
     give_ups = int(ctx.kernel_ms(9)[0])
     if give_ups:
@@ -951,6 +1059,7 @@ def main():
         # it -- and the units the index pass decodes itself (few, long elements) are not theirs at all
         achieved = (sum_c + u_bytes - sparse_bytes) / ((dec_ms + dec2_ms) * 1e-3) / 1e9 if dec_ms > 0 else 0.0
         step_achieved = (sum_c + u_bytes) / ((dec_ms + dec2_ms + idx_ms) * 1e-3) / 1e9 if dec_ms > 0 else 0.0
+        step_traffic = measured_step_traffic(nb, args.only)
         line = {
             "metric": "GB/s uncompressed throughput (compress + decompress), 4 GiB many-block corpus",
             "value": round(value, 3),
@@ -983,6 +1092,11 @@ def main():
                 "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "traffic": measured_traffic(nb, args.only)[0],
                 "traffic_source": measured_traffic(nb, args.only)[1],  # (null traffic: why)
+                # the whole step (index pass + both decode launches): every unit's bytes over the three kernels' time, the
+                # PMC bytes of the three, and how much more than the algorithmic bytes that is
+                "frac_step": round(step_achieved / HBM_PEAK_GBPS, 5),
+                "traffic_step": step_traffic,
+                "traffic_over_algorithmic": round(step_traffic / (sum_c + u_bytes), 4) if step_traffic else None,
                 "kernel": RING_KERNEL,  # (ring window; <65536> takes the units it passes on)
                 "kernel_ms": round(dec_ms, 4),  # (HIP events; rocprof's average for this kernel agrees)
                 "kernel_ms_both_decode_launches": round(dec_ms + dec2_ms, 4),  # what `achieved` divides by
@@ -1013,12 +1127,16 @@ def main():
                 "kernel_ms": round(enc_ms, 4),
                 "algorithmic_bytes_per_launch": sum_c + u_bytes,
             },
+            "library": {"path": os.path.relpath(hip.LIB_PATH, ROOT), "overridden": bool(hip.LIB_OVERRIDDEN)},
             "sharded_compress": sharded,
             # compress + decompress of the same bytes, one after the other (BASELINE's metric names both)
             "roundtrip_GBps": round(world * u_bytes / (t_enc + elapsed / args.steps) / 1e9, 3),
             # one genuine framed stream (10-byte identifier + one chunk per block), stream and output in HBM
             "framed_compress_GBps": round(world * u_bytes / t_fenc / 1e9, 3),
-            "framed_decompress_GBps": round(world * u_bytes / t_fdec / 1e9, 3),
+            "framed_decompress_GBps": round(world * u_bytes / t_fdec / 1e9, 3),  # (mean over the timed calls)
+            "framed_decompress_best_GBps": round(world * u_bytes / t_fdec_min / 1e9, 3),
+            "framed_decompress_calls": len(fdec_ts), "framed_compress_calls": len(fenc_ts),
+            "framed_decompress_over_value": round((world * u_bytes / t_fdec / 1e9) / value, 4),
             "framed_chunk_walk_ms": round(walk_ms, 3),
         }
         if world == 1 and not args.no_cpu:

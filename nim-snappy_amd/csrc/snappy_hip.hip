@@ -1082,8 +1082,10 @@ extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, in
   }
   uint64_t total_in = 0;
   for (int k = 0; k < n; k++) total_in += in_len[k];
-  const uint64_t S = stage_blocks ? stage_blocks : ((uint64_t)1 << 40);
   const uint64_t total_blocks = (total_in + kMaxBlockLen - 1) / kMaxBlockLen;
+  // (a stage never needs to be larger than the input: keeps S * 65536 and S * n far from wrapping)
+  if (stage_blocks > total_blocks) stage_blocks = total_blocks ? total_blocks : 1;
+  const uint64_t S = stage_blocks ? stage_blocks : ((uint64_t)1 << 40);
   const uint64_t per_stage = S * (uint64_t)n;  // blocks of a full stage
   const uint64_t n_stages = stage_blocks ? (total_blocks + per_stage - 1) / per_stage : 1;
   // what context k holds of stage j, in bytes, by the layout above -- and the caller's lengths must agree with it
@@ -1114,6 +1116,8 @@ extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, in
   std::mutex mu;
   std::condition_variable cv;
   bool failed = false;
+  int first_status = SNAPPY_HIP_OK;  // the FIRST failure (the others then fail because of it): what the caller is told
+  std::string first_err;
   std::vector<int> status(n, SNAPPY_HIP_OK);
   std::vector<std::string> errs(n);
   const int unit = framed ? kUnitFrame : kUnitBody;
@@ -1133,6 +1137,10 @@ extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, in
       status[k] = st;
       errs[k] = g_last_error;
       std::lock_guard<std::mutex> lk(mu);
+      if (!failed) {
+        first_status = st;
+        first_err = g_last_error;
+      }
       failed = true;
       for (uint64_t j = 0; j < n_stages; j++)
         if (sizes[j * n + k] == ~0ull) sizes[j * n + k] = 0;  // (nobody waits for me)
@@ -1195,6 +1203,7 @@ extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, in
                                              (uint32_t*)d_sizes, nullptr)) ||
             (st = snappy_hip_pack_d(c, (const uint8_t*)d_slots, kSlotStride, (const uint32_t*)d_sizes, nb, at_dev[j],
                                     (uint8_t*)d_out, (uint64_t*)d_offsets, nullptr))) {
+          (void)hipStreamSynchronize(copy_stream);  // (earlier stages' downloads into the caller's buffer may be in flight)
           (void)hipStreamDestroy(copy_stream);
           (void)hipEventDestroy(packed_ev);
           return fail(st);
@@ -1239,6 +1248,10 @@ extern "C" int snappy_hip_compress_shards_staged(snappy_hip_ctx* const* ctxs, in
     }
     worker(0);
     for (auto& t : th) t.join();
+  }
+  if (first_status) {
+    g_last_error = first_err;
+    return first_status;
   }
   for (int k = 0; k < n; k++)
     if (status[k]) {

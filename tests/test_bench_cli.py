@@ -99,3 +99,47 @@ def test_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.measured_traffic(65536, None)[0] is None
     (root / "profiles" / "r02_traffic.json").write_text(json.dumps(dict(kern, csrc_sha256=build_id.csrc_sha256(str(root)))))
     assert bench.measured_traffic(65536, None)[0] == 7.0e9
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_step_traffic_sums_the_steps_kernels(tmp_path, monkeypatch):
+    """roofline.traffic_step = the PMC bytes of the index pass + the ring launch + the passed-on units' launch, from ONE
+    profile of these kernel sources; missing any of the three: null"""
+    import json
+    import build_id
+    bench = _bench_module()
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    (root / "nim-snappy_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "nim-snappy_amd" / "csrc" / "k.h").write_text("// kernel\n")
+    (root / "include" / "snappy_hip.h").write_text("// abi\n")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    sha = build_id.csrc_sha256(str(root))
+    kern = {k: {"total_bytes": float(i + 1) * 1e9} for i, k in enumerate(bench.STEP_KERNELS)}
+    (root / "profiles" / "r01_traffic.json").write_text(json.dumps({"csrc_sha256": sha, "kernels": kern}))
+    assert bench.measured_step_traffic(65536, None) == 6.0e9
+    assert bench.measured_step_traffic(1024, None) is None
+    del kern[bench.STEP_KERNELS[0]]
+    (root / "profiles" / "r01_traffic.json").write_text(json.dumps({"csrc_sha256": sha, "kernels": kern}))
+    assert bench.measured_step_traffic(65536, None) is None
+
+
+def test_abi_caller_on_preallocated_buffers(orc):
+    """the README-table legs time a library's C ABI on preallocated buffers (no Python-side copies inside the call):
+    the caller class, here with the oracle on both sides -- same bytes, the source back, raw and framed"""
+    from conftest import golden_file
+    bench = _bench_module()
+    src = golden_file("html")
+    cap_raw, cap_fr = orc.max_compressed_len(len(src)), orc.max_compressed_len_framed(len(src))
+    a = bench.AbiCaller(orc.lib, "sor_", src, cap_raw, cap_fr)
+    b = bench.AbiCaller(orc.lib, "sor_", src, cap_raw, cap_fr)
+    a.check_against(b)
+    assert a.raw[:a.raw_len].tobytes() == orc.encode(src) and a.fr[:a.fr_len].tobytes() == orc.encode_framed(src)

@@ -287,6 +287,18 @@ def test_full_size_round_trip_properties(hip, orc, torch_mod):
         f_at += want.size
     assert f_at == flen
     assert sha_gpu.hexdigest() == sha_orc.hexdigest()
+    # ... and uncompressFramed (snappy.nim:169-267) of that ONE stream at full size: (read, written) = (all, all), every
+    # byte back, with the CRCs checked; a stream with one CRC byte flipped in its last chunk is a crcMismatch, and an
+    # output buffer one byte short stops at the last chunk's header (the resume contract, test_framed.nim:38-59)
+    del d_out
+    d_back = torch.empty(nb * 65536, dtype=torch.uint8, device="cuda")
+    assert ctx.uncompress_framed(d_fstream, flen, d_back, nb * 65536) == (0, flen, nb * 65536)
+    assert bool(torch.equal(d_back, d_in))
+    last_hdr = flen - int(csz[c - 1])  # (the last chunk: 4 bytes of header + its declared length)
+    st, rd, wr = ctx.uncompress_framed(d_fstream, flen, d_back, nb * 65536 - 1)
+    assert (st, rd, wr) == (0, last_hdr, (nb - 1) * 65536), (st, rd, wr, last_hdr)
+    d_fstream[last_hdr + 4] ^= 0x40
+    assert ctx.uncompress_framed(d_fstream, flen, d_back, nb * 65536)[0] == 3  # crcMismatch
     ctx.close()
 
 
@@ -368,7 +380,15 @@ def test_bench_contract_and_two_rank_path(hip):
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["dtype"] == "u8" and j["vs_baseline"] is None and j["value"] > 0
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "traffic_step",
+                "traffic_over_algorithmic")) <= set(j["roofline"])
+    assert 0 < j["roofline"]["frac_step"] < 1
+    assert j["framed_decompress_calls"] == 2 and j["framed_decompress_best_GBps"] >= j["framed_decompress_GBps"] > 0
+    assert j["library"] == {"path": os.path.join("nim-snappy_amd", "libsnappy_hip.so"), "overridden": False}
+    # a variant library is refused unless asked for
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SNAPPY_HIP_LIBRARY=os.path.join(root, "nim-snappy_amd", "libsnappy_hip.so")))
+    assert ref.returncode == 2 and "SNAPPY_HIP_LIBRARY" in ref.stderr
     assert j["roofline_compress"]["frac"] > 0 and j["sharded_compress"]["n_shards"] == 1
     assert j["sharded_compress"]["equals_single_gpu_sha256"] is True
     # --gpus 2 with NO launcher on the command line: bench.py starts its two ranks itself
@@ -391,6 +411,31 @@ def test_bench_contract_and_two_rank_path(hip):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
                          capture_output=True, text=True, timeout=300, env=env3)
     assert bad.returncode != 0
+
+
+def test_bench_eight_ranks_share_the_gpu(hip):
+    """the shape of the driver's 8-GPU run on a one-GPU box: eight ranks (gloo, all on this GPU), 128 blocks each; the
+    sharded compress of the same fixed total (1 024 blocks, stages going round eight ranks) gives the stream one rank
+    gives, digest for digest"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--blocks", "128", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None)
+    outs = {}
+    for n in (1, 8):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + common,
+                           capture_output=True, text=True, timeout=1200, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[n] = json.loads(lines[0])
+    assert outs[8]["n_gpus"] == 8 and outs[8]["value"] > 0
+    a, b = outs[1]["sharded_compress"], outs[8]["sharded_compress"]
+    assert b["n_shards"] == 8 and len(b["shard_bytes"]) == 8 and b["equals_single_gpu_sha256"] is True
+    assert a["total_blocks"] == b["total_blocks"] == 1024
+    assert a["stream_sha256_tree64MiB"] == b["stream_sha256_tree64MiB"] and a["stream_bytes"] == b["stream_bytes"]
 
 
 def test_sharded_compress_tool_two_ranks(hip):
@@ -643,6 +688,21 @@ def test_shards_from_one_process_land_in_one_host_buffer(hip, orc, torch_mod):
             assert offs[-1] == written
         with pytest.raises(ValueError):  # lengths that are not what the stage layout gives the contexts
             hip.compress_shards(ctxs, d_ins, lens, out.data_ptr(), cap, framed=False, stage_blocks=S)
+    # EIGHT contexts (one per GPU of a node; here all on this box's GPU): stages of 5 blocks go round them, the n stage
+    # sizes are exchanged under the mutex, every context downloads beside its next stage -- the oracle's bytes
+    ctx8 = ctxs + [hip.Context(0) for _ in range(6)]
+    for S in (5, 1):
+        parts = [bytearray() for _ in range(8)]
+        for i, at in enumerate(range(0, len(src), S * B)):
+            parts[i % 8] += src[at:at + S * B]
+        d_st = [_dev(torch, np.frombuffer(bytes(q) if q else b"\0", dtype=np.uint8)) for q in parts]
+        cap = hip.max_compressed_len_framed(len(src))
+        out = torch.zeros(cap, dtype=torch.uint8, pin_memory=True)
+        written, offs = hip.compress_shards(ctx8, d_st, [len(q) for q in parts], out.data_ptr(), cap, framed=True, stage_blocks=S)
+        assert out[:written].numpy().tobytes() == orc.encode_framed(src), S
+        assert len(offs) == 9 and offs[-1] == written
+    for c in ctx8[2:]:
+        c.close()
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shards_one_process.py"), "--gpus", "2", "--same-gpu",
                          "--total-gib", "0.25", "--check", "--reps", "1"], capture_output=True, text=True, timeout=600)
     assert rc.returncode == 0, rc.stderr[-2000:]
