@@ -208,23 +208,31 @@ __device__ __forceinline__ void encode_one_block(const EncodeParams& prm, const 
   // bytes), a lane where a copy starts writes the copy (emitCopy :81-125; lengths <= 64 only, so
   // one element of 2 or 3 bytes).  No lane writes more than three bytes; a lane with fewer writes
   // the rest to its sink behind the buffer -- no branches.
+  // (selects written as bit masks: left as ?: the compiler makes EXEC-mask branches of them, five per round, each a
+  // scalar save / restore pair and a taken branch on a lone wave's path)
   auto emit_round = [&]() {
     dpend = false;
     const uint64_t LIT = ballot(dp_lit);
     const uint64_t here = LIT >> lane;  // bit 0: this lane, bit k: lane + k
-    const bool lit = here & 1;
-    const bool run_start = lit && !(((LIT << 1) >> lane) & 1);
+    const uint32_t lit = (uint32_t)here & 1u;
+    const uint32_t run_start = lit & ~(uint32_t)((LIT << 1) >> lane) & 1u;
     const uint32_t rl = ctz64(~here);   // literal bytes from here to the next copy
-    const bool is_copy = (dp_ms >> lane) & 1;
+    const uint32_t is_copy = (uint32_t)(dp_ms >> lane) & 1u;
     const uint32_t length = dp_len, offset = dp_off;
-    const bool c2 = length >= 12 || offset >= 2048;  // :114-125
-    const uint32_t cval = c2 ? ((((length - 1) << 2) | 2) | (offset << 8))
-                             : ((((offset >> 8) << 5) | ((length - 4) << 2) | 1) | ((offset & 255) << 8));
-    const bool tag2 = rl > 60;
-    const uint32_t lval = !run_start ? dp_byte
-                          : (tag2 ? ((60u << 2) | ((rl - 1) << 8) | (dp_byte << 16)) : (((rl - 1) << 2) | (dp_byte << 8)));
-    const uint32_t val = lit ? lval : cval;
-    const uint32_t nb = lit ? (run_start ? (tag2 ? 3 : 2) : 1) : (is_copy ? (c2 ? 3 : 2) : 0);
+    const uint32_t c2m = 0u - (uint32_t)((length >= 12) | (offset >= 2048));  // :114-125
+    const uint32_t cv2 = (((length - 1) << 2) | 2) | (offset << 8);
+    const uint32_t cv1 = (((offset >> 8) << 5) | ((length - 4) << 2) | 1) | ((offset & 255) << 8);
+    const uint32_t cval = (cv2 & c2m) | (cv1 & ~c2m);
+    const uint32_t t2m = 0u - (uint32_t)(rl > 60);
+    const uint32_t lv2 = (60u << 2) | ((rl - 1) << 8) | (dp_byte << 16);
+    const uint32_t lv1 = ((rl - 1) << 2) | (dp_byte << 8);
+    const uint32_t rsm = 0u - run_start;
+    const uint32_t lval = (((lv2 & t2m) | (lv1 & ~t2m)) & rsm) | (dp_byte & ~rsm);
+    const uint32_t litm = 0u - lit;
+    const uint32_t val = (lval & litm) | (cval & ~litm);
+    const uint32_t nb_l = 1 + run_start + (run_start & t2m & 1u);  // a byte; the run's first: its tag of one or two bytes too
+    const uint32_t nb_c = is_copy * (2 + (c2m & 1u));
+    const uint32_t nb = (nb_l & litm) | (nb_c & ~litm);
     uint32_t total;
     const uint32_t at = ofill + wave_excl_scan(nb, lane, &total);
     const uint32_t sink = kObSize + 64 + lane;
@@ -536,6 +544,8 @@ __device__ __forceinline__ void encode_one_block(const EncodeParams& prm, const 
         }
       }
       uint4 cv;
+      // (candidates that lie inside the LDS window read from there instead -- fewer lanes in the gather -- measured 16 % slower:
+      // two EXEC-masked paths and five more LDS reads a lane cost more than the lanes saved; profiles/README.md)
       __builtin_memcpy(&cv, in + cand, 16);
       tick(1);
       drain();  // the previous round's elements, while the candidates are in flight

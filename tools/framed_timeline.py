@@ -4,9 +4,9 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-di = [i for i, n in enumerate(names) if "decode_indexed_kernelILj32768" in n]
+di = [i for i, n in enumerate(names) if "decode_indexed_kernel" in n and "16384" in n]
 i0 = di[-1]
-lo, hi = max(0, i0 - 16), min(len(rows), i0 + 10)
+lo, hi = max(0, i0 - 24), min(len(rows), i0 + 10)
 t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:hi]:
     print("%8.1f %8.1f us  %s  grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
