@@ -23,7 +23,11 @@
  * buffers that its calls reuse.  Every entry point makes its context's device current for the
  * call and restores the caller's.
  *
- * Environment (read once, by the host-buffer calls only; the device-resident API reads none):
+ * Environment (read once, by the host-buffer calls only; the device-resident API reads one, at context creation):
+ *   SNAPPY_HIP_ENC_GWAVES    "g" or "g,min_blocks" (every context): of four encoder workgroups, g (0..4, default 4) run a
+ *                            second wave whose hash table lies in global memory (csrc/encode_kernel.h) -- eight blocks a
+ *                            CU instead of four -- on batches of at least min_blocks blocks (default: twice what the
+ *                            GPU's LDS-table waves take at once).  Output bytes never depend on it.
  *   SNAPPY_HIP_DEVICE        GPU of the pooled contexts (default 0)
  *   SNAPPY_HIP_HOST_BATCH    blocks per upload/compute/download batch (64 .. 65536, default 2048)
  *   SNAPPY_HIP_PIN_HOST      0 pageable copies (default) / 1, 2 page-lock the caller's buffers per call, per batch

@@ -46,7 +46,7 @@ thread_local std::string g_last_error;
 
 // Debug knobs (profiles/README.md) are read only by builds with -DSNAPPY_HIP_DEBUG.  The shipped library reads
 // four tuning knobs of the host-buffer calls, once (include/snappy_hip.h documents them): SNAPPY_HIP_DEVICE,
-// SNAPPY_HIP_HOST_BATCH, SNAPPY_HIP_PIN_HOST, SNAPPY_HIP_COPY_THREADS; the device-resident API reads none.
+// SNAPPY_HIP_HOST_BATCH, SNAPPY_HIP_PIN_HOST, SNAPPY_HIP_COPY_THREADS; every context reads SNAPPY_HIP_ENC_GWAVES when it is created.
 #ifdef SNAPPY_HIP_DEBUG
 inline const char* dbg_env(const char* name) { return getenv(name); }
 #else
