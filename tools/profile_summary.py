@@ -30,7 +30,7 @@ for f in ("bench.json", "bench_profiled.json"):
                 j = json.loads(line)
                 print("* `%s`: value %.1f %s, ms_per_step %.3f, roofline %s, compress %.2f GB/s" % (
                     f, j["value"], j["unit"], j["ms_per_step"], json.dumps(j["roofline"]), j.get("compress_GBps", 0)))
-print("\n## kernel-trace --stats (bench.py --steps 5 --warmup 1 --no-cpu)\n")
+print("\n## kernel-trace --stats (bench.py --steps 5 --warmup 1 --no-cpu --shard-gib 0)\n")
 for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
     print("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|")
     for row in csv.DictReader(open(f)):
@@ -82,7 +82,7 @@ kern = {k: {"read_bytes": 2.0 * v.get("FETCH_SIZE", 0.0), "write_bytes": v.get("
         for k, v in tr.items() if "kernel" in k and not k.startswith("void")}
 with open(os.path.join(out, "traffic.json"), "w") as fh:
     json.dump({"csrc_sha256": build_id.csrc_sha256(),  # the kernel sources this was measured on (bench.py checks it)
-               "workload": "bench.py --steps 2 --warmup 1 --no-cpu (65536 x 64 KiB blocks, class mix default, seed 0x5EED5AA9), 1 x MI355X",
+               "workload": "bench.py --steps 2 --warmup 1 --no-cpu --shard-gib 0 (65536 x 64 KiB blocks, class mix default, seed 0x5EED5AA9), 1 x MI355X",
                "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = KB x 1024, "
                          "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section); mean per dispatch.  FETCH_SIZE counts "
                          "the L2's requests to the fabric, Infinity Cache hits included",
