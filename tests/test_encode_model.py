@@ -85,3 +85,33 @@ def test_wide_round_model_equals_oracle(orc, R):
     # the measured reason: wide rounds advance far less than R positions each
     assert st["wide_positions"] / st["wide_rounds"] < 0.9 * R
     assert st["wide_cut"] > 0.3 * st["wide_rounds"]
+
+
+def test_second_waves_scratch_finds_the_lanes_of_a_slot():
+    """encode_one_block<true> (the table in global memory) finds the lanes of a round that share a table slot through a
+    1 024-entry LDS scratch instead of through the table: the model of that exchange (tools/encode_model.py) against the
+    definitions -- the nearest earlier lane with my 14-bit hash; of the inserted lanes of a hash the last one writes -- on
+    random rounds, rounds of few distinct hashes, and hashes that share their low ten bits (another slot's lane in between)"""
+    import random
+    import encode_model as em
+    rnd = random.Random(0x5C7A)
+    for trial in range(400):
+        kind = trial % 4
+        if kind == 0:
+            hs = [rnd.randrange(1 << 14) for _ in range(64)]
+        elif kind == 1:
+            pool = [rnd.randrange(1 << 14) for _ in range(rnd.randrange(1, 9))]
+            hs = [rnd.choice(pool) for _ in range(64)]
+        elif kind == 2:  # the same low ten bits, different high bits: shared scratch entries
+            low = [rnd.randrange(1 << 10) for _ in range(rnd.randrange(1, 5))]
+            hs = [rnd.choice(low) | (rnd.randrange(3) << 10) for _ in range(64)]
+        else:
+            hs = [(rnd.randrange(1 << 14) if rnd.random() < 0.7 else 0x155) for _ in range(64)]
+        want = []
+        for i, h in enumerate(hs):
+            earlier = [j for j in range(i) if hs[j] == h]
+            want.append(earlier[-1] if earlier else 64)
+        assert em.scratch_predecessors(hs) == want, trial
+        ins = [rnd.random() < 0.55 for _ in range(64)]
+        want_w = [ins[i] and not any(ins[j] and hs[j] == hs[i] for j in range(i + 1, 64)) for i in range(64)]
+        assert em.scratch_writers(hs, ins) == want_w, trial

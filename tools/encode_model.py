@@ -305,3 +305,67 @@ def encode_block(data, stats=None, wide=None):
         stats["rounds"] = rounds
         stats["dense_rounds"] = dense_rounds
     return bytes(out)
+
+
+# ---- round 5: the second wave's scratch (encode_kernel.h, encode_one_block<true>) ------------------------------------
+# Its table lies in global memory, so the lanes of a round that share a table slot find each other in LDS: a scratch of
+# 1 024 entries indexed by the hash's low ten bits, through which the lanes go IN LANE ORDER (ds_mskor_rtn_b32 serves the
+# lanes of one address in ascending order), each leaving (valid, the hash's other bits, its lane) and taking what the lane
+# before it on that entry left.  These two functions are that procedure; tests/test_encode_model.py checks them against the
+# definitions they implement: "the nearest earlier lane of the round on my table slot" and "of the inserted lanes on one
+# slot, the last one writes".
+SCRATCH_BITS = 10
+
+
+def scratch_predecessors(hashes):
+    """dep[i] = the nearest earlier lane with hashes[i], or 64 -- through the scratch exchange, with the lanes whose entry
+    was last used by another slot's lane settled the way the kernel settles them (a look over all lanes of that hash)"""
+    scratch = {}
+    dep = [64] * len(hashes)
+    ambiguous = []
+    for lane, h in enumerate(hashes):  # ascending service order
+        key, tag = h & ((1 << SCRATCH_BITS) - 1), h >> SCRATCH_BITS
+        prev = scratch.get(key)
+        scratch[key] = (tag, lane)
+        if prev is not None:
+            if prev[0] == tag:
+                dep[lane] = prev[1]
+            else:
+                ambiguous.append(lane)
+    done = set()
+    for j in ambiguous:  # (one pass per hash value among them: ballot(h == hj))
+        if hashes[j] in done:
+            continue
+        done.add(hashes[j])
+        group = [i for i, h in enumerate(hashes) if h == hashes[j]]
+        for a, b in zip(group, group[1:]):
+            dep[b] = a
+    return dep
+
+
+def scratch_writers(hashes, inserted):
+    """which lanes write their position to the table: of the INSERTED lanes of a slot the last one -- the second exchange,
+    among the inserted lanes only, and a look at who is on the entry last"""
+    scratch = {}
+    for lane, h in enumerate(hashes):
+        if inserted[lane]:
+            scratch[h & ((1 << SCRATCH_BITS) - 1)] = (h >> SCRATCH_BITS, lane)
+    writer = [False] * len(hashes)
+    ambiguous = []
+    for lane, h in enumerate(hashes):
+        if not inserted[lane]:
+            continue
+        tag, last = scratch[h & ((1 << SCRATCH_BITS) - 1)]
+        if last == lane:
+            writer[lane] = True
+        elif tag != (h >> SCRATCH_BITS) or last < lane:
+            ambiguous.append(lane)
+    done = set()
+    for j in ambiguous:
+        if hashes[j] in done:
+            continue
+        done.add(hashes[j])
+        group = [i for i, h in enumerate(hashes) if h == hashes[j] and inserted[i]]
+        for i in group:
+            writer[i] = i == group[-1]
+    return writer
