@@ -268,6 +268,21 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   unsigned long long tA = 0, tW = 0, tC = 0, tt0 = 0, tt1 = 0, tt2 = 0;  // DEBUG (SPLIT, prm.idx != nullptr)
   const bool dbgt = SPLIT && prm.idx != nullptr;
   if (SPLIT && wave == 0) post(0, 0, 0, 0, false);
+#ifndef IDX_NO_EARLY_PERIOD
+  if (!SPLIT && prm.sparse && n <= 4096) {
+    // a unit that is one literal + copies of one offset is recognised from its stream and written at once: no walk
+    // (sparse_kernel.h, early_period_unit with the total unknown); anything else: the walk below
+    uint32_t tot = 0;
+    if (early_period_unit(in0, n, prm.out + prm.out_off[u], kPeriodTotalUnknown, s_tab, limit, exact, &tot)) {
+      if (prm.sparse_counters && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + tot);
+        atomicAdd(prm.sparse_counters + 2, 1u);
+      }
+      return finish(kDoneEarly, tot);
+    }
+    wave_fence();
+  }
+#endif
 
   for (uint32_t c0 = wave * kChunk; c0 < n && !ended; c0 += W * kChunk) {
     const uint32_t rs = c0 + lane * kRegion;  // my region's first stream position

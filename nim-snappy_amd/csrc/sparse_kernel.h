@@ -381,8 +381,17 @@ __device__ __forceinline__ void early_literal_unit(const uint8_t* src, uint8_t* 
 // byte behind the literal is a copy2 tag with that offset" proves that those are the element starts (decoder.nim:112:
 // 1 <= offset <= the literal's length).  One wave; lds: 8 224 bytes (the stream, at most 4 KiB, and the image).
 // Returns false if the unit is not of this kind (nothing written).
-__device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n, uint8_t* gout, uint32_t total, uint32_t* lds) {
+// total == kPeriodTotalUnknown (round 5): called BEFORE the unit's chain has been walked -- the stream's shape is then all
+// there is to go by, and it is enough: one literal (its length bytes obeying the 61-byte rule, decoder.nim:54-57) followed
+// by nothing but whole copy2 elements of one offset <= the literal's length is a valid element sequence, its total is the
+// literal's length plus the sum of the copies' lengths (a reduction over at most 1 365 tags), and that total must be
+// what the caller wants (exact: the declared length, snappy.nim:107-108; else at most `limit`).  Anything else returns
+// false and the walk decides.  A period unit then never walks its chain (~40 of the ~125 us it held a wave slot).
+constexpr uint32_t kPeriodTotalUnknown = 0xffffffffu;
+__device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n, uint8_t* gout, uint32_t total, uint32_t* lds,
+                                                  uint32_t limit = 0, bool exact = false, uint32_t* total_out = nullptr) {
   const uint32_t lane = lane_id();
+  const bool total_known = total != kPeriodTotalUnknown;
   if (n > 4096 || n < 5 || ((uintptr_t)gout & 15) != 0) return false;
   uint8_t* const s_str = reinterpret_cast<uint8_t*>(lds);
   uint8_t* const s_rep = s_str + 4096;
@@ -404,7 +413,8 @@ __device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n
     L0 = b + 1;
   }
   const uint32_t h = 1 + lenlen;
-  if (L0 == 0 || L0 >= total || h + L0 + 3 > n || (n - h - L0) % 3 != 0) return false;
+  if (!total_known && lenlen && n - 1 < 61) return false;  // (decoder.nim:54-57: the walk gives the verdict)
+  if (L0 == 0 || (total_known && L0 >= total) || L0 > kMaxBlockLen || h + L0 + 3 > n || (n - h - L0) % 3 != 0) return false;
   const uint32_t q0 = h + L0;  // the first copy
   const uint32_t roff = s_str[q0 + 1] | ((uint32_t)s_str[q0 + 2] << 8);
   if ((s_str[q0] & 3) != 2 || roff < 1 || roff > L0 || roff > 4096) return false;
@@ -415,6 +425,15 @@ __device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n
     ok = ok && (s_str[t] & 3) == 2 && (s_str[t + 1] | ((uint32_t)s_str[t + 2] << 8)) == roff;
   }
   if (ballot(!ok)) return false;
+  if (!total_known) {
+    uint32_t sum = 0;
+    for (uint32_t k = lane; k < nrec; k += 64) sum += ((uint32_t)s_str[q0 + 3 * k] >> 2) + 1;
+    uint32_t all;
+    (void)wave_excl_scan(sum, lane, &all);
+    total = L0 + all;
+    if (total > kMaxBlockLen || (exact ? total != limit : total > limit)) return false;
+    if (total_out) *total_out = total;
+  }
   // image of the period: rep[i] = out[L0 - offset + i mod offset] for i < M + 16, M a multiple of the offset of about 4 KiB
   const uint32_t M = roff * (4096 / roff);  // (> 1024: the writer's phase advances by 1024 a trip)
   const uint32_t pb = q0 - roff;            // stream position of the period's first byte
