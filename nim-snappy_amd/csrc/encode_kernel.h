@@ -1284,9 +1284,9 @@ __device__ __forceinline__ void encode_one_block(const EncodeParams& prm, const 
 
 // Persistent workgroups of two waves: each wave takes the next block of the launch order until none is left (one counter;
 // a returning atomic per block, ~1 us against the ~50-1 500 us a block takes).  Wave 0 works with the table in LDS; wave 1
-// -- in g_per4 of every four workgroups of an XCD -- with its table in global memory (encode_one_block<true>): two more
-// waves per CU for every such workgroup, whose 32 KiB tables (g_per4 x 256 KiB per CU quad... at most 4 MiB per XCD at
-// g_per4 = 4) have to stay in the XCD's 4 MiB L2 beside the input: g_per4 is the host's choice (snappy_hip.hip).
+// -- in g_per4 of every four workgroups of an XCD -- with its table in global memory (encode_one_block<true>): one more
+// wave per such workgroup, up to eight waves a CU, whose 32 KiB tables (g_per4 MiB per XCD) compete for the XCD's 4 MiB L2
+// with the input; what misses it is served by the Infinity Cache.  g_per4 is the host's choice (snappy_hip.hip: 4).
 __global__ __launch_bounds__(64 * kEncWaves) void encode_blocks_kernel(EncodeParams prm) {
   __shared__ __attribute__((aligned(16))) uint16_t s_table[kMaxTableSize + 64];  // + one sink slot per lane
   __shared__ __attribute__((aligned(16))) uint8_t s_ob[kEncWaves][kObCap];

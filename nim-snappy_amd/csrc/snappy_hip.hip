@@ -118,7 +118,6 @@ struct snappy_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // work that runs beside the main stream's (a framed stream's stored chunks)
   hipEvent_t side_done = nullptr;
-  hipEvent_t side_fork = nullptr;  // (recorded on the main stream: what the side stream's work waits for)
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
   uint16_t* d_tag_lut = nullptr;   // [256] the decode front end's tag table (decode2_kernel.h)
@@ -264,7 +263,6 @@ int ctx_init(snappy_hip_ctx* c) {
     HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
   }
   HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
@@ -343,7 +341,6 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_seq_step);
   (void)hipFree(c->d_counters);
   if (c->side_done) (void)hipEventDestroy(c->side_done);
-  if (c->side_fork) (void)hipEventDestroy(c->side_fork);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
