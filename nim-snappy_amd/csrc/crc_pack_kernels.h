@@ -306,6 +306,18 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const uint32_t* keys
   }
 }
 
+// The index pass takes the same units in a SPREAD order: unit i of its launch is entry (i * stride) mod n of the sorted list,
+// stride ~ n / golden ratio and coprime to n (a low-discrepancy walk through the list: neighbours in the launch come from
+// all over it).  The sorted order runs the corpus's kinds one after the other -- the one-literal units (the longest streams:
+// a copy at HBM rate), then text and html (walked: bound by latency, 18 waves a CU), the periods last (64 KiB written
+// from a 4 KiB stream) -- so the pass was bound by HBM, then by latency, then by HBM again; spread, the copies and writes run
+// beside the walks: index pass 2.08 -> 1.93 ms per 4 GiB.  (The indexed decoder keeps the sorted order: there like next to
+// like is what pays.)
+__global__ __launch_bounds__(256) void order_spread_kernel(const uint32_t* perm, uint64_t n, uint64_t stride, uint32_t* spread) {
+  const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (i < n) spread[i] = perm[(i * stride) % n];
+}
+
 // The encoder's blocks have no length to go by, so blocks that look alike are put next to each
 // other: the sketch of a block is the number of distinct values (of 512 possible) among the hashes
 // of the 512 aligned dwords of its first 2 KiB -- a handful for runs and short periods, a few hundred

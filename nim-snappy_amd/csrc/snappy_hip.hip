@@ -640,8 +640,25 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     if (n_units >= 512 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
       void* d_perm;
       if ((st = launch_order(c, d_in_len, n_units, kOrderByLength, 15, 0, s, &d_perm))) return st;
-      ip.order = (const uint32_t*)d_perm;
       dp.order = (const uint32_t*)d_perm;
+      ip.order = (const uint32_t*)d_perm;
+      if (!dbg_env("SNAPPY_HIP_NO_SPREAD")) {  // the index pass: the sorted list walked with a golden-ratio stride (crc_pack_kernels.h)
+        void* d_spread;
+        if ((st = ws_get(c, 22, n_units * 4, &d_spread))) return st;
+        uint64_t stride = (uint64_t)((double)n_units * 0.6180339887498949) | 1;
+        auto gcd = [](uint64_t a, uint64_t b) {
+          while (b) {
+            const uint64_t t = a % b;
+            a = b;
+            b = t;
+          }
+          return a;
+        };
+        while (gcd(stride, n_units) != 1) stride += 2;
+        LAUNCH(order_spread_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_perm, n_units,
+               stride % n_units, (uint32_t*)d_spread);
+        ip.order = (const uint32_t*)d_spread;
+      }
     }
     if (d_crc && kD2FusedCrc && !dbg_env("SNAPPY_HIP_NO_FUSED_CRC")) {  // the CRC comes out of the decode kernel's flush
       if ((st = ws_get(c, 14, n_units, &d_done))) return st;
