@@ -743,7 +743,7 @@ __device__ __forceinline__ void encode_one_block(const EncodeParams& prm, const 
 #ifndef ENC_NO_LONG_SPLIT
           if (mlast + nel <= 64) {
             const uint32_t j = lane - mlast;                       // (lanes below mlast: huge)
-            const uint32_t lj = j < k64 ? 64u : ((j == k64) & (has60 != 0) ? 60u : rem - 60 * has60);
+            const uint32_t lj = j < k64 ? 64u : (((j == k64) & (has60 != 0)) ? 60u : rem - 60 * has60);
             const bool mine_el = j < nel;
             dp_len = mine_el ? lj : dp_len;
             dp_off = mine_el ? off_l : dp_off;

@@ -637,7 +637,9 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     dp.unit = unit;
     dp.tag_lut = c->d_tag_lut;
     if (const char* e = dbg_env("SNAPPY_HIP_DBG")) dp.dbg = atoi(e);
-    if (n_units >= 512 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {  // launch order: similar lengths together, longest first
+    // launch order: similar lengths together, longest first (1 024 units are resident all at once -- four ring workgroups
+    // a CU: no order to choose, and five small launches less in front of a small call)
+    if (n_units > 1024 && c->launch_order && !dbg_env("SNAPPY_HIP_NO_ORDER")) {
       void* d_perm;
       if ((st = launch_order(c, d_in_len, n_units, kOrderByLength, 15, 0, s, &d_perm))) return st;
       dp.order = (const uint32_t*)d_perm;
@@ -1826,20 +1828,25 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 
 // Block starts of one raw buffer by the speculative parallel walk of split_kernels.h.  d_tags = the
 // tag stream (behind the varint) in device memory.  Returns 0 (d_blk[k] = stream position of block
-// k's first element for every k), a status > 0 (the walk saw the whole stream: its verdict stands), or
-// -1: not applicable (the chain is not complete within the looks, an invalid or foreign element lies on it, a
-// candidate list overflowed, an element straddles a block boundary).
+// k's first element for every k -- if the chain was complete: d_bad[0] bit 8 says when it was not), a status > 0
+// (the walk saw the whole stream: its verdict stands), or -1: not applicable (the chain is not complete within the
+// looks, an invalid or foreign element lies on it, a candidate list overflowed, an element straddles a block
+// boundary).
+// looks == false: everything is enqueued without a look from the host -- six launches of the walk (the first does
+// nearly all of the work, a later one is a load per wave that got nothing new), the marking, the placement; the
+// verdict kernels note whether the root's chain reached the stream's end, and the caller, who looks once behind the
+// decode, comes back with looks == true if it did not: the procedure from its start, with the host looking at the chain
+// every four launches.
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s, uint32_t* d_ol, uint32_t* d_bad, const uint64_t** d_total,
-                      const uint32_t** d_flags) {
-  // rounds before the first look at the chain (text-like data is complete by then), between later looks
-  // (a handful of late candidates), looks before the serial walk takes over
-  constexpr int kRoundsFirst = 4, kRoundsLater = 4, kMaxLooks = 6;
+                      const uint32_t** d_flags, bool looks) {
+  constexpr int kLaunchesFirst = 6, kLaunchesLater = 4, kMaxLooks = 6;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
+  const uint32_t nwg = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 16 KiB of staged stream each)
   const size_t nodes = (size_t)nseg * kSplitCand;
   void* base;
-  // per node: ent, ext, ob, two jump tables (4 bytes each), reach (1); per segment: entry, outb (4), out_at (8)
-  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 16 + 8 + 64 + 64, &base);
+  // per node: ent, ext, ob, two jump tables (4 bytes each), reach (1); per segment: entry, outb (4), out_at (8); per wave: dirty
+  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 16 + (size_t)nwg * 4 + 8 + 64 + 64, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
   uint64_t* out_at = (uint64_t*)q;
@@ -1857,15 +1864,17 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   q += (size_t)nseg * 4;
   uint32_t* outb = (uint32_t*)q;
   q += (size_t)nseg * 4;
+  uint32_t* dirty = (uint32_t*)q;
+  q += (size_t)nwg * 4;
   uint32_t* counters = (uint32_t*)q;  // [0] candidates added, [1] overflow
   q += 32;
   uint32_t* flags = (uint32_t*)q;
   q += 32;
   uint8_t* reach = q;
-  {  // ent and ext: no candidates but the root, nothing walked; counters and flags; block starts, lengths, verdict
+  {  // ent and ext: no candidates but the root, nothing walked; counters, flags, dirty; block starts, lengths, verdict
     const uint32_t ig = (uint32_t)((nodes * 2 + 255) / 256 < 1024 ? (nodes * 2 + 255) / 256 : 1024);
-    LAUNCH(split_init_kernel, dim3(ig), dim3(256), 0, s, ent, (uint64_t)nodes * 2, counters, d_blk, (uint32_t)(nblk + 1), d_ol,
-           (uint32_t)nblk, d_bad);
+    LAUNCH(split_init_kernel, dim3(ig), dim3(256), 0, s, ent, (uint64_t)nodes * 2, counters, dirty, nwg, d_blk,
+           (uint32_t)(nblk + 1), d_ol, (uint32_t)nblk, d_bad);
   }
   SplitParams sp{};
   sp.in = d_tags;
@@ -1875,29 +1884,29 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.ext = ext;
   sp.ob = ob;
   sp.counters = counters;
+  sp.dirty = dirty;
   sp.entry = entry;
   sp.outb = outb;
   sp.flags = flags;
   sp.out_at = out_at;
   sp.blk_in = d_blk;
   sp.nblk = (uint32_t)nblk;
+  sp.bad = d_bad;
+  sp.local_max = kSplitLocalMax;
+  if (const char* e = dbg_env("SNAPPY_HIP_SPLIT_LOCAL")) sp.local_max = (uint32_t)atoi(e);  // DEBUG
   const uint32_t grid = (nseg + 255) / 256;
   const uint32_t ngrid = (uint32_t)((nodes + 255) / 256);
-  const uint32_t wgrid = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 16 KiB of staged stream each)
   HIP_TRY(hipFuncSetAttribute((const void*)split_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   HIP_TRY(hipFuncSetAttribute((const void*)split_locate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
   while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
   bool done = false;
   int cur = 0;
-  for (int look = 0; look < kMaxLooks && !done; look++) {
-    // (a look at the chain is a dozen pointer-jump launches over every node and a synchronisation: 0.5 ms for the 2 M
-    // segments of a 1 GiB buffer, as much as two and a half rounds -- big streams walk eight rounds between later looks)
-    const int rounds_later = nseg > (1u << 20) ? 2 * kRoundsLater : kRoundsLater;
-    for (int r = 0; r < (look == 0 ? kRoundsFirst : rounds_later); r++) {
+  for (int look = 0; look < (looks ? kMaxLooks : 1) && !done; look++) {
+    for (int r = 0; r < (look == 0 ? kLaunchesFirst : kLaunchesLater); r++) {
       LaunchTimer lt(c, s, 7);
       sp.first = look == 0 && r == 0;
-      LAUNCH(split_walk_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
+      LAUNCH(split_walk_kernel, dim3(nwg), dim3(kSplitWg), kSplitStage, s, sp);
     }
     // is the real chain complete?  mark what the root reaches; its last pointer tells
     LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach);
@@ -1905,6 +1914,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     for (int k = 0; k < steps; k++, cur ^= 1)
       LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach);
     HIP_TRY(hipGetLastError());
+    if (!looks) break;
     uint32_t h_root = 0, h_cnt[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&h_root, jump[cur], 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h_cnt, counters, 8, hipMemcpyDeviceToHost, s));
@@ -1916,12 +1926,12 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     // may have dropped the candidate the chain needs: one more look, then the serial walk
     else if (h_root == kSplitBad || (h_cnt[1] && look >= 1)) return -1;
   }
-  if (!done) return -1;
-  LAUNCH(split_select_kernel, dim3(grid), dim3(256), 0, s, sp, (const uint8_t*)reach);
+  if (looks && !done) return -1;
+  LAUNCH(split_select_kernel, dim3(grid), dim3(256), 0, s, sp, (const uint8_t*)reach, (const uint32_t*)jump[cur]);
   {  // out_at = exclusive prefix sum of outb (tile sums live in the jump tables, which are free now)
     const uint32_t tiles = (nseg + kSplitTile - 1) / kSplitTile;
-    uint32_t* tile_sum = jump[0];
-    uint64_t* tile_base = (uint64_t*)jump[1];  // [tiles + 1] (nodes * 4 bytes >= that)
+    uint32_t* tile_sum = jump[cur ^ 1];
+    uint64_t* tile_base = (uint64_t*)ext;  // [tiles + 1] (nodes * 4 bytes >= that; the walks' exits are not needed any more)
     LAUNCH(split_tile_sums_kernel, dim3(tiles), dim3(256), 0, s, (const uint32_t*)outb, nseg, tile_sum);
     LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, (const uint32_t*)tile_sum, (uint64_t)tiles, (uint64_t)0, tile_base);
     LAUNCH(split_tile_scan_kernel, dim3(tiles), dim3(256), 0, s, (const uint32_t*)outb, nseg, (const uint64_t*)tile_base, out_at);
@@ -1929,7 +1939,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   // (the total -- snappy.nim:107-108 -- and the last walk's flags are judged on the device, by split_table_kernel: the
   // host looks once, behind the decode; a total that is not the declared length writes no block start beyond the table)
   (void)len;
-  LAUNCH(split_locate_kernel, dim3(wgrid), dim3(kSplitWg), kSplitStage, s, sp);
+  LAUNCH(split_locate_kernel, dim3(nwg), dim3(kSplitWg), kSplitStage, s, sp);
   HIP_TRY(hipGetLastError());
   *d_total = out_at + nseg;
   *d_flags = flags;
@@ -1962,83 +1972,92 @@ int uncompress_split_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, uint32
   if ((st = ws_get(c, 10, 64, &d_one))) return st;
   hipStream_t s = on ? on : c->stream;  // (the device-resident entry point passes the caller's stream on)
   if (!d_in_res && (st = stage_upload(c, d_in, in, n, s, true))) return st;
-  uint32_t* d_bad = (uint32_t*)d_one + 6;  // d_one[6]: the split's verdict (split_table_kernel)
-  const uint64_t* d_total = nullptr;
-  const uint32_t* d_flags = nullptr;
+  uint32_t* d_bad = (uint32_t*)d_one + 6;  // d_one[6..8]: the split's verdict, the root's last pointer, overflow (split_kernels.h)
   // first the speculative parallel walk (split_kernels.h); the one-workgroup walk below is its fallback
-  // (a look at the chain is ~20 small launches and a synchronisation, ~0.4 ms before anything is decoded: below
-  // ~200 KiB of stream the one-workgroup walk, 1 GB/s, is there first)
+  // (the marking is ~a dozen small launches, ~0.1 ms before anything is decoded: below ~200 KiB of stream the
+  // one-workgroup walk, 1 GB/s, is there first)
   constexpr size_t kSpecMinStream = 192 << 10;
-  const int spec = (dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT") || n - hdr < kSpecMinStream)
-                       ? -1
-                       : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk, s,
-                                           (uint32_t*)d_ol, d_bad, &d_total, &d_flags);
-  if (spec > 0) return spec;
-  if (spec < 0) {  // (not tried, or given up: the one-workgroup walk starts from a clean table)
-    d_total = nullptr;
-    d_flags = nullptr;
-    HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
-  }
-  // the splitter's one unit: [in_off u64 | in_len u32 | out_cap u32 | out_len u32 | status u32]
-  struct {
-    uint64_t in_off;
-    uint32_t in_len, out_cap, out_len, status;
-  } one = {0, (uint32_t)n, (uint32_t)len, 0, 0};
-  HIP_TRY(hipMemcpyAsync(d_one, &one, sizeof(one), hipMemcpyHostToDevice, s));
-  IndexParams ip{};
-  ip.in = (const uint8_t*)d_in;
-  ip.in_off = (const uint64_t*)d_one;
-  ip.in_len = (const uint32_t*)((uint8_t*)d_one + 8);
-  ip.out_cap = (const uint32_t*)((uint8_t*)d_one + 12);
-  ip.out_len = (uint32_t*)((uint8_t*)d_one + 16);
-  ip.status = (uint32_t*)((uint8_t*)d_one + 20);
-  ip.n_units = 1;
-  ip.unit = kUnitRaw;
-  ip.blk_in = (uint32_t*)d_blk;
-  unsigned long long* d_sdbg = nullptr;
-  if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
-    HIP_TRY(hipMalloc((void**)&d_sdbg, 64));
-    HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
-    ip.idx = (uint32_t*)d_sdbg;
-  }
-  if (spec < 0) LAUNCH(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
-  if (d_sdbg) {
-    unsigned long long h[8];
-    HIP_TRY(hipMemcpyAsync(h, d_sdbg, 64, hipMemcpyDeviceToHost, s));
+  const bool try_spec = !dbg_env("SNAPPY_HIP_NO_SPEC_SPLIT") && n - hdr >= kSpecMinStream;
+  // attempt 0: the speculative walk with nothing looked at by the host before the decode is done; attempt 1, if its chain
+  // was not complete: the same with looks; then (or at once, for a small stream) the one-workgroup walk
+  for (int attempt = try_spec ? 0 : 2; attempt < 3; attempt++) {
+    const uint64_t* d_total = nullptr;
+    const uint32_t* d_flags = nullptr;
+    const int spec = attempt == 2 ? -1
+                                  : split_blocks_spec(c, (const uint8_t*)d_in + hdr, (uint32_t)(n - hdr), len, nblk, (uint32_t*)d_blk,
+                                                      s, (uint32_t*)d_ol, d_bad, &d_total, &d_flags, attempt == 1);
+    if (spec > 0) return spec;
+    if (spec < 0 && attempt < 2) {
+      attempt = 1;  // (given up: the one-workgroup walk starts from a clean table)
+      continue;
+    }
+    if (spec < 0) {
+      d_total = nullptr;
+      d_flags = nullptr;
+      HIP_TRY(hipMemsetAsync(d_blk, 0xff, (nblk + 1) * 4, s));
+      HIP_TRY(hipMemsetAsync(d_bad, 0, 12, s));
+      HIP_TRY(hipMemsetAsync(d_ol, 0, nblk * 4, s));
+      // the splitter's one unit: [in_off u64 | in_len u32 | out_cap u32 | out_len u32 | status u32]
+      struct {
+        uint64_t in_off;
+        uint32_t in_len, out_cap, out_len, status;
+      } one = {0, (uint32_t)n, (uint32_t)len, 0, 0};
+      HIP_TRY(hipMemcpyAsync(d_one, &one, sizeof(one), hipMemcpyHostToDevice, s));
+      IndexParams ip{};
+      ip.in = (const uint8_t*)d_in;
+      ip.in_off = (const uint64_t*)d_one;
+      ip.in_len = (const uint32_t*)((uint8_t*)d_one + 8);
+      ip.out_cap = (const uint32_t*)((uint8_t*)d_one + 12);
+      ip.out_len = (uint32_t*)((uint8_t*)d_one + 16);
+      ip.status = (uint32_t*)((uint8_t*)d_one + 20);
+      ip.n_units = 1;
+      ip.unit = kUnitRaw;
+      ip.blk_in = (uint32_t*)d_blk;
+      unsigned long long* d_sdbg = nullptr;
+      if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG
+        HIP_TRY(hipMalloc((void**)&d_sdbg, 64));
+        HIP_TRY(hipMemsetAsync(d_sdbg, 0, 64, s));
+        ip.idx = (uint32_t*)d_sdbg;
+      }
+      LAUNCH(index_units_kernel<true>, dim3(1), dim3(64 * kSplitWaves), 0, s, ip);
+      if (d_sdbg) {
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpyAsync(h, d_sdbg, 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const double nch = (double)((n + kChunk - 1) / kChunk) / kSplitWaves;
+        fprintf(stderr, "SPLIT STATS wave 0, ticks per own chunk: tables %.0f, mail wait %.0f, chain %.0f\n", h[0] / nch,
+                h[1] / nch, h[2] / nch);
+        (void)hipFree(d_sdbg);
+      }
+      // the one-workgroup walk's verdict (the speculative walk has given its own)
+      HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
+      if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
+    }
+    // the blocks as units, on the device (no trip to the host in between); d_bad: a block without a start, ...
+    LAUNCH(split_table_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_blk, (uint32_t)nblk,
+           (uint32_t)(n - hdr), hdr, len, (uint64_t*)d_io, (uint32_t*)d_il, (uint64_t*)d_oo, (uint32_t*)d_oc, d_bad, d_total,
+           d_flags);
+    if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nblk,
+                       (int)kUnitBody, nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
+                       (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
+      return st;
+    // every block to its full length?  (e.g. a copy that reaches into an earlier block: not)  One look at three words.
+    LAUNCH(split_verdict_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_st, (const uint32_t*)d_ol,
+           (uint32_t)nblk, len, d_bad);
+    uint32_t h_bad[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_bad, d_bad, 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const double nch = (double)((n + kChunk - 1) / kChunk) / kSplitWaves;
-    fprintf(stderr, "SPLIT STATS wave 0, ticks per own chunk: tables %.0f, mail wait %.0f, chain %.0f\n", h[0] / nch,
-            h[1] / nch, h[2] / nch);
-    (void)hipFree(d_sdbg);
-  }
-  if (spec < 0) {  // the one-workgroup walk's verdict (the speculative walk has given its own)
-    HIP_TRY(hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (one.status == kNeedsStreamKernel || one.status == kNeedsOnePass) return -1;
-    if (one.status != kOk) return (int)one.status;  // the walk saw the whole stream: its verdict stands
-  }
-  // the blocks as units, on the device (no trip to the host in between); d_one[6]: a block without a start
-  LAUNCH(split_table_kernel, dim3((uint32_t)((nblk + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_blk, (uint32_t)nblk,
-         (uint32_t)(n - hdr), hdr, len, (uint64_t*)d_io, (uint32_t*)d_il, (uint64_t*)d_oo, (uint32_t*)d_oc, d_bad, d_total,
-         d_flags);
-  if ((st = decode_d(c, (const uint8_t*)d_in, (const uint64_t*)d_io, (const uint32_t*)d_il, nblk,
-                     (int)kUnitBody, nullptr, (uint8_t*)d_out, (const uint64_t*)d_oo,
-                     (const uint32_t*)d_oc, (uint32_t*)d_ol, (uint32_t*)d_st, true, s)))
-    return st;
-  std::vector<uint32_t> stv(nblk), olv(nblk);
-  uint32_t h_bad = 0;
-  HIP_TRY(hipMemcpyAsync(stv.data(), d_st, nblk * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(olv.data(), d_ol, nblk * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (h_bad & 2) return SNAPPY_HIP_INVALID_INPUT;  // (the speculative walk saw the whole stream: its verdict stands)
-  if (h_bad) return -1;
-  for (size_t k = 0; k < nblk; k++) {
-    const uint64_t oo = (uint64_t)k * kMaxBlockLen;
-    const uint32_t oc = (uint32_t)(len - oo < kMaxBlockLen ? len - oo : kMaxBlockLen);
-    if (stv[k] != kOk || olv[k] != oc) return -1;  // e.g. a copy that reaches into an earlier block
+    if (attempt == 0 && (h_bad[0] & 8)) {  // the chain was not complete behind six launches (or never will be)
+      if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
+        fprintf(stderr, "SPLIT without looks: root -> %08x, overflow %u: again, with looks\n", h_bad[1], h_bad[2]);
+      if (h_bad[1] == kSplitBad) attempt = 1;  // (an invalid or foreign element on the chain: for the serial walk to judge)
+      continue;
+    }
+    if (h_bad[0] & 2) return SNAPPY_HIP_INVALID_INPUT;  // (the speculative walk saw the whole stream: its verdict stands)
+    if (h_bad[0]) return -1;
+    break;
   }
   if (!d_out_res && (st = stage_download(c, out, d_out, (size_t)len, s, false))) return st;
   *written = (size_t)len;
