@@ -1832,25 +1832,27 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // (the walk saw the whole stream: its verdict stands), or -1: not applicable (the chain is not complete within the
 // looks, an invalid or foreign element lies on it, a candidate list overflowed, an element straddles a block
 // boundary).
-// looks == false: everything is enqueued without a look from the host -- six launches of the walk (the first does
-// nearly all of the work, a later one is a load per wave that got nothing new), the marking, the placement; the
-// verdict kernels note whether the root's chain reached the stream's end, and the caller, who looks once behind the
-// decode, comes back with looks == true if it did not: the procedure from its start, with the host looking at the chain
-// every four launches.
+// looks == false: everything is enqueued without a look from the host -- the bulk launch, six tail rounds (one with an
+// empty queue is a load per wave), the marking, the placement; the verdict kernels note whether the root's chain
+// reached the stream's end, and the caller, who looks once behind the decode, comes back with looks == true if it did
+// not: the procedure from its start, the host reading every round's queue length (up to twelve rounds) before it marks.
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s, uint32_t* d_ol, uint32_t* d_bad, const uint64_t** d_total,
                       const uint32_t** d_flags, bool looks) {
-  constexpr int kLaunchesFirst = 6, kLaunchesLater = 4, kMaxLooks = 6;
+  constexpr uint32_t kRoundsBlind = 6;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
-  const uint32_t nwg = (nseg + kSplitWg - 1) / kSplitWg;  // (the walks: one wave and 16 KiB of staged stream each)
+  const uint32_t nwg = (nseg + kSplitWg - 1) / kSplitWg;  // (the bulk launch: one wave and 16 KiB of staged stream each)
   const size_t nodes = (size_t)nseg * kSplitCand;
   void* base;
-  // per node: ent, ext, ob, two jump tables (4 bytes each), reach (1); per segment: entry, outb (4), out_at (8); per wave: dirty
-  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 16 + (size_t)nwg * 4 + 8 + 64 + 64, &base);
+  // per node: ent, ext, ob, two jump tables (4 bytes each; the queues until the marking), reach (1); per segment: entry,
+  // outb (4), out_at (8), the first walk's checkpoints (8), entry, exit, output bytes (4)
+  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 36 + 8 + 64 + 64, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
   uint64_t* out_at = (uint64_t*)q;
   q += ((size_t)nseg + 1) * 8;
+  uint64_t* cp = (uint64_t*)q;
+  q += (size_t)nseg * 8;
   uint32_t* ent = (uint32_t*)q;
   q += nodes * 4;
   uint32_t* ext = (uint32_t*)q;
@@ -1864,17 +1866,21 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   q += (size_t)nseg * 4;
   uint32_t* outb = (uint32_t*)q;
   q += (size_t)nseg * 4;
-  uint32_t* dirty = (uint32_t*)q;
-  q += (size_t)nwg * 4;
-  uint32_t* counters = (uint32_t*)q;  // [0] candidates added, [1] overflow
-  q += 32;
+  uint32_t* f_entry = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* f_code = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* f_ob = (uint32_t*)q;
+  q += (size_t)nseg * 4;
+  uint32_t* counters = (uint32_t*)q;  // [0] candidates added, [1] overflow, [2 + r] round r's queue length
+  q += 64;
   uint32_t* flags = (uint32_t*)q;
   q += 32;
   uint8_t* reach = q;
-  {  // ent and ext: no candidates but the root, nothing walked; counters, flags, dirty; block starts, lengths, verdict
+  {  // ent and ext: no candidates but the root, nothing walked; counters, flags; block starts, lengths, verdict
     const uint32_t ig = (uint32_t)((nodes * 2 + 255) / 256 < 1024 ? (nodes * 2 + 255) / 256 : 1024);
-    LAUNCH(split_init_kernel, dim3(ig), dim3(256), 0, s, ent, (uint64_t)nodes * 2, counters, dirty, nwg, d_blk,
-           (uint32_t)(nblk + 1), d_ol, (uint32_t)nblk, d_bad);
+    LAUNCH(split_init_kernel, dim3(ig), dim3(256), 0, s, ent, (uint64_t)nodes * 2, counters, d_blk, (uint32_t)(nblk + 1), d_ol,
+           (uint32_t)nblk, d_bad);
   }
   SplitParams sp{};
   sp.in = d_tags;
@@ -1884,7 +1890,11 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.ext = ext;
   sp.ob = ob;
   sp.counters = counters;
-  sp.dirty = dirty;
+  sp.cp = cp;
+  sp.f_entry = f_entry;
+  sp.f_code = f_code;
+  sp.f_ob = f_ob;
+  sp.q_cap = (uint32_t)nodes;
   sp.entry = entry;
   sp.outb = outb;
   sp.flags = flags;
@@ -1893,40 +1903,68 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.nblk = (uint32_t)nblk;
   sp.bad = d_bad;
   sp.local_max = kSplitLocalMax;
-  if (const char* e = dbg_env("SNAPPY_HIP_SPLIT_LOCAL")) sp.local_max = (uint32_t)atoi(e);  // DEBUG
+  sp.budget = kSplitBudget;
+  sp.hops = kSplitHops;
+  if (const char* e = dbg_env("SNAPPY_HIP_SPLIT_KNOBS")) {  // DEBUG: "local rounds,budget,hops"
+    unsigned a = kSplitLocalMax, b = kSplitBudget, h = kSplitHops;
+    sscanf(e, "%u,%u,%u", &a, &b, &h);
+    sp.local_max = a, sp.budget = b, sp.hops = h;
+  }
   const uint32_t grid = (nseg + 255) / 256;
   const uint32_t ngrid = (uint32_t)((nodes + 255) / 256);
-  HIP_TRY(hipFuncSetAttribute((const void*)split_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
+  HIP_TRY(hipFuncSetAttribute((const void*)split_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
+  HIP_TRY(hipFuncSetAttribute((const void*)split_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
   HIP_TRY(hipFuncSetAttribute((const void*)split_locate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitStage));
+  {
+    LaunchTimer lt(c, s, 7);
+    sp.q_out = jump[0];
+    sp.q_out_count = counters + 2;
+    LAUNCH(split_bulk_kernel, dim3(nwg), dim3(kSplitWg), kSplitStage, s, sp);
+  }
+  if (dbg_env("SNAPPY_HIP_STATS")) {  // DEBUG: the bulk launch's phases (debug builds time them)
+    uint32_t h[8];
+    HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    fprintf(stderr, "SPLIT bulk, us per wave: stage %.1f first walk %.1f hand on + summary %.1f push %.1f local rounds %.1f (%u waves)\n",
+            h[3] / 100.0 / nwg, h[4] / 100.0 / nwg, h[5] / 100.0 / nwg, h[6] / 100.0 / nwg, h[7] / 100.0 / nwg, nwg);
+    HIP_TRY(hipMemsetAsync(flags + 3, 0, 20, s));
+  }
+  const uint32_t tgrid = nwg < 2048 ? nwg : 2048;
+  for (uint32_t r = 0; r + 1 < kSplitMaxRounds; r++) {
+    if (!looks && r == kRoundsBlind) break;
+    if (looks) {  // (the fallback's pace: a look a round)
+      uint32_t h_n = 0;
+      HIP_TRY(hipMemcpyAsync(&h_n, counters + 2 + r, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (dbg_env("SNAPPY_HIP_STATS")) fprintf(stderr, "SPLIT round %u: %u nodes queued\n", r, h_n);  // DEBUG
+      if (h_n == 0) break;
+    }
+    LaunchTimer lt(c, s, 7);
+    sp.q_in = jump[r & 1];
+    sp.q_in_count = counters + 2 + r;
+    sp.q_out = jump[(r + 1) & 1];
+    sp.q_out_count = counters + 3 + r;
+    LAUNCH(split_tail_kernel, dim3(tgrid), dim3(kSplitWg), kSplitStage, s, sp);
+  }
+  // is the real chain complete?  mark what the root reaches; its last pointer tells
   int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
   while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
-  bool done = false;
+  LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach);
   int cur = 0;
-  for (int look = 0; look < (looks ? kMaxLooks : 1) && !done; look++) {
-    for (int r = 0; r < (look == 0 ? kLaunchesFirst : kLaunchesLater); r++) {
-      LaunchTimer lt(c, s, 7);
-      sp.first = look == 0 && r == 0;
-      LAUNCH(split_walk_kernel, dim3(nwg), dim3(kSplitWg), kSplitStage, s, sp);
-    }
-    // is the real chain complete?  mark what the root reaches; its last pointer tells
-    LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach);
-    cur = 0;
-    for (int k = 0; k < steps; k++, cur ^= 1)
-      LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach);
-    HIP_TRY(hipGetLastError());
-    if (!looks) break;
+  for (int k = 0; k < steps; k++, cur ^= 1)
+    LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach);
+  HIP_TRY(hipGetLastError());
+  if (looks) {
     uint32_t h_root = 0, h_cnt[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&h_root, jump[cur], 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h_cnt, counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (dbg_env("SNAPPY_HIP_STATS"))  // DEBUG
-      fprintf(stderr, "SPLIT look %d: root -> %08x, candidates added %u, overflow %u\n", look, h_root, h_cnt[0], h_cnt[1]);
-    if (h_root == kSplitEnd) done = true;
-    // an invalid or foreign element on the chain (for the serial walk to judge); a list that overflowed
-    // may have dropped the candidate the chain needs: one more look, then the serial walk
-    else if (h_root == kSplitBad || (h_cnt[1] && look >= 1)) return -1;
+      fprintf(stderr, "SPLIT look: root -> %08x, candidates added %u, overflow %u\n", h_root, h_cnt[0], h_cnt[1]);
+    // an invalid or foreign element on the chain, a list that overflowed and may have dropped the candidate the chain
+    // needs, rounds that never ended: for the serial walk to judge
+    if (h_root != kSplitEnd) return -1;
   }
-  if (looks && !done) return -1;
   LAUNCH(split_select_kernel, dim3(grid), dim3(256), 0, s, sp, (const uint8_t*)reach, (const uint32_t*)jump[cur]);
   {  // out_at = exclusive prefix sum of outb (tile sums live in the jump tables, which are free now)
     const uint32_t tiles = (nseg + kSplitTile - 1) / kSplitTile;
@@ -1939,7 +1977,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   // (the total -- snappy.nim:107-108 -- and the last walk's flags are judged on the device, by split_table_kernel: the
   // host looks once, behind the decode; a total that is not the declared length writes no block start beyond the table)
   (void)len;
-  LAUNCH(split_locate_kernel, dim3(nwg), dim3(kSplitWg), kSplitStage, s, sp);
+  if (nblk > 1) LAUNCH(split_locate_kernel, dim3((uint32_t)((nblk - 1 + kSplitWg - 1) / kSplitWg)), dim3(kSplitWg), kSplitStage, s, sp);
   HIP_TRY(hipGetLastError());
   *d_total = out_at + nseg;
   *d_flags = flags;

@@ -20,14 +20,18 @@
 // encoder: the caller falls back to the serial walk).  All input-side checks of decodeAllTags are made
 // by the walk (decode_element, index_kernel.h).
 //
-// Round 5: a launch of the walk kernel is not one round any more.  A wave (64 segments, their 16 KiB in LDS)
-// runs LOCAL rounds until none of its segments has a candidate that is not walked -- what a walk hands to a
-// segment of the same wave is walked without another launch; only what crosses into another wave's segments
-// may need the next launch (that wave's dirty flag; a wave without it leaves after one load).  And a walk stops
-// where it falls into step with the lane's first walk of the same launch (which leaves a checkpoint in each of
-// the segment's eight 32-byte blocks: its first element start there): it takes over that walk's exit and, by
-// walking that walk again up to the meeting point (a few elements), its output bytes -- the second walk of a
-// segment costs a few elements instead of a hundred.  tools/split_model.py is this procedure on the CPU.
+// Round 5: the rounds are not launches over every segment any more.  ONE launch (split_bulk_kernel: a wave per 64
+// segments, their 16 KiB staged in LDS) walks every segment from its guess -- the segment's FIRST walk, which leaves a
+// checkpoint in each of the segment's eight 32-byte blocks (its first element start there) and a summary (entry, exit,
+// output bytes, whether the exit was handed on) -- and then, in a few local rounds, what those walks hand to segments
+// of the same wave: a later walk stops where it enters a block at the first walk's checkpoint (it has fallen into
+// step with it), and takes over that walk's exit and, by walking that walk again up to the meeting point, its output
+// bytes.  Most second walks meet the first within a dozen elements; the few of a wave that do not would hold up its
+// other 63 lanes for the length of a whole walk each, so a local walk has a budget of elements, and what is not done by
+// then -- and what is handed to another wave's segment -- goes on a QUEUE of nodes.  The later rounds are launches of
+// split_tail_kernel over that queue, a LANE per node whatever its segment (the lane stages its own segment), each
+// round's new candidates on the next round's queue: the stragglers of all waves side by side, as many lanes as there
+// are stragglers.  tools/split_model.py is this procedure on the CPU.
 #pragma once
 
 #include "common.h"
@@ -60,10 +64,19 @@ struct SplitParams {
   uint32_t* ent;          // [nseg * kSplitCand] candidate entries (all ones: empty)
   uint32_t* ext;          // [nseg * kSplitCand] exit of the walk from it (kSplitPending: not walked, kSplitBad)
   uint32_t* ob;           // [nseg * kSplitCand] output bytes of the elements it walked
-  uint32_t* counters;     // [0] candidates added, [1] a segment's list overflowed
-  uint32_t* dirty;        // [waves] a candidate was handed to one of the wave's segments (cleared by the wave when it looks)
-  int first;              // the first launch: every segment also walks from its guess, its first byte
-  uint32_t local_max;     // local rounds a launch (kSplitLocalMax; DEBUG: fewer)
+  uint32_t* counters;     // [0] candidates added, [1] a segment's list (or the queue) overflowed, [2 + r] round r's queue length
+  // the segment's first walk (the bulk launch): checkpoints, entry, exit code, output bytes | handed on << 31
+  uint64_t* cp;           // [nseg]
+  uint32_t* f_entry;      // [nseg]
+  uint32_t* f_code;       // [nseg]
+  uint32_t* f_ob;         // [nseg]
+  // the queue of nodes to walk: this round's (tail launch) and the next one's
+  const uint32_t* q_in;
+  const uint32_t* q_in_count;
+  uint32_t* q_out;
+  uint32_t* q_out_count;
+  uint32_t q_cap;
+  uint32_t local_max, budget, hops;  // kSplitLocalMax, kSplitBudget, kSplitHops (DEBUG builds: others, for measurements)
   // after the marking
   uint32_t* entry;        // [nseg] the entry of the real chain (all ones: it passes over the segment)
   uint32_t* outb;         // [nseg] output bytes of the elements that start in the segment
@@ -77,15 +90,14 @@ struct SplitParams {
 // Everything the split starts from, in one launch (eight fills and copies of a few bytes each cost 0.2 ms of
 // launch gaps in front of the first walk): candidate lists empty but for the root, nothing walked, counters and
 // flags zero, no block start known, no unit length, no verdict.
-__global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint64_t n_ent_ext, uint32_t* counters16,
-                                                         uint32_t* dirty, uint32_t n_dirty, uint32_t* blk, uint32_t n_blk,
-                                                         uint32_t* out_len, uint32_t n_len, uint32_t* bad3) {
+__global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint64_t n_ent_ext, uint32_t* counters24,
+                                                         uint32_t* blk, uint32_t n_blk, uint32_t* out_len, uint32_t n_len,
+                                                         uint32_t* bad3) {
   const uint64_t t = blockIdx.x * 256ull + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
   for (uint64_t i = t; i < n_ent_ext; i += stride) ent_ext[i] = i == 0 ? kSplitTrusted : 0xffffffffu;  // (node 0: position 0)
-  for (uint64_t i = t; i < n_dirty; i += stride) dirty[i] = 0;
   for (uint64_t i = t; i < n_blk; i += stride) blk[i] = 0xffffffffu;
   for (uint64_t i = t; i < n_len; i += stride) out_len[i] = 0;
-  if (t < 16) counters16[t] = 0;
+  if (t < 24) counters24[t] = 0;  // (the counters' sixteen words and the flags' eight behind them)
   if (t < 3) bad3[t] = 0;
 }
 
@@ -98,7 +110,10 @@ __global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint
 constexpr uint32_t kSplitWg = 64;
 constexpr uint32_t kSplitRow = kSplitSeg + 4;
 constexpr uint32_t kSplitStage = kSplitWg * kSplitRow;  // 16 640 bytes: 13 pieces of LDS, nine waves a CU
-constexpr uint32_t kSplitLocalMax = kSplitWg + 2;       // local rounds a launch (a chain handed on segment by segment)
+constexpr uint32_t kSplitLocalMax = 4;    // rounds of the bulk launch: the first walks, then what they hand on inside the wave
+constexpr uint32_t kSplitBudget = 24;     // elements a local walk may take (most meet the first walk within a dozen)
+constexpr uint32_t kSplitMaxRounds = 13;  // tail launches at most (their queue lengths live in counters[2 .. 15])
+constexpr uint32_t kSplitNoNode = 0xffffffffu;
 extern __shared__ __attribute__((aligned(16))) uint8_t s_split_dyn[];
 
 // the element at offset `off` of the lane's segment (row: its staged bytes): false = invalid
@@ -171,13 +186,13 @@ __device__ __forceinline__ void split_stage(const SplitParams& p, uint8_t* stage
 
 
 // `pos` becomes a (trusted) candidate of the segment it lies in, if it is not one already; the slot, or kSplitCand.
-// A new one raises its wave's dirty flag -- behind the entry: a wave that sees the flag sees the entry.
-__device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos, uint32_t* n_added) {
+__device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos, bool* is_new, uint32_t* n_added) {
   uint32_t* e = p.ent + (pos / kSplitSeg) * kSplitCand;
+  *is_new = false;
   for (uint32_t c = 0; c < kSplitCand; c++) {
     const uint32_t old = atomicCAS(&e[c], 0xffffffffu, pos | kSplitTrusted);
     if (old == 0xffffffffu) {
-      __hip_atomic_store(&p.dirty[pos / (kSplitSeg * kSplitWg)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *is_new = true;
       ++*n_added;
       return c;
     }
@@ -187,20 +202,36 @@ __device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos
   return kSplitCand;
 }
 
-// A walk, from w.pos to the segment's end.  MODE 1: the lane's first walk of this launch leaves CHECKPOINTS -- for each of
-// the segment's eight 32-byte blocks, the first element start in it (a byte of cp: offset in the block + 1, 0: none).
-// MODE 2: a later walk compares its own first start in every block with the checkpoint: equal = it has fallen into step
-// with the first walk (*hit, the walk stops there).  MODE 0: neither.  (A bitmap of every start would find the meeting
-// point a few elements sooner, for a register file indexed by position: sixteen selects at every block border.)
+// The nodes the lanes of a wave want walked in the next round, onto its queue: one atomic a wave.  (Wave-uniform call.)
+__device__ __forceinline__ void split_push(const SplitParams& p, uint32_t node) {
+  const uint64_t m = __ballot(node != kSplitNoNode);
+  if (!m) return;
+  uint32_t base = 0;
+  const uint32_t lane = threadIdx.x & 63;
+  if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(p.q_out_count, (uint32_t)__builtin_popcountll(m));
+  base = __shfl(base, __builtin_ctzll(m), 64);
+  if (node != kSplitNoNode) {
+    const uint32_t i = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+    if (i < p.q_cap) p.q_out[i] = node;
+    else p.counters[1] = 1;  // (what does not fit is lost: the chain may be incomplete, like with a list that overflowed)
+  }
+}
+
+// A walk, from w.pos to the segment's end (at most `budget` elements).  MODE 1: the segment's first walk leaves
+// CHECKPOINTS -- for each of the segment's eight 32-byte blocks, the first element start in it (a byte of cp: offset in
+// the block + 1, 0: none).  MODE 2: a later walk compares its own first start in every block with the checkpoint:
+// equal = it has fallen into step with the first walk (*hit, the walk stops there).  MODE 0: neither.  (A bitmap of
+// every start would find the meeting point a few elements sooner, for a register file indexed by position: sixteen
+// selects at every block border.)
 struct SplitWalk {
   uint32_t pos, out, clean, last_size;
   bool bad;
 };
 template <int MODE>
 __device__ __forceinline__ void split_walk_loop(const uint8_t* row, uint32_t seg_lo, uint32_t seg_hi, uint32_t n, uint64_t* cp,
-                                                SplitWalk* w, bool* hit) {
+                                                SplitWalk* w, bool* hit, uint32_t budget) {
   uint32_t jprev = 8;
-  while (w->pos < seg_hi) {
+  while (w->pos < seg_hi && budget-- != 0) {
     const uint32_t off = w->pos - seg_lo;
     if (MODE) {
       const uint32_t j = off >> 5, field = (off & 31) + 1;
@@ -228,134 +259,233 @@ __device__ __forceinline__ void split_walk_loop(const uint8_t* row, uint32_t seg
   }
 }
 
-// One launch: every wave with something new walks its candidates in local rounds (see the head of this file).
-__global__ __launch_bounds__(kSplitWg) void split_walk_kernel(SplitParams p) {
+// A walk that reached its segment's end on its own hands its exit on -- if its last kSplitClean elements were native.
+// *handed: the exit is a candidate now (or was one).  Returns the node that still has to be walked (the exit's, or the
+// last one of the follow-through), kSplitNoNode if there is none or it is a segment of the caller's own wave (my_wg),
+// whose owner will see it in its list.
+__device__ __forceinline__ uint32_t split_hand_on(const SplitParams& p, const SplitWalk& w, uint32_t my_wg, bool* handed,
+                                                  uint32_t* n_added) {
+  *handed = false;
+  if (w.pos >= p.n || w.clean < kSplitClean) return kSplitNoNode;
+  uint32_t pos = w.pos;
+  bool is_new;
+  uint32_t slot = split_add(p, pos, &is_new, n_added);
+  *handed = slot < kSplitCand;
+  uint32_t open = is_new ? (pos / kSplitSeg) * kSplitCand + slot : kSplitNoNode;
+  // Follow-through.  Long literals back to back (incompressible blocks: one literal of 64 KiB each) are
+  // a chain that would be discovered ONE literal per round -- the segment a literal ends in learns the
+  // candidate from the walk of the segment the literal starts in.  So a walk that leaves its segment
+  // with a long literal and lands on another one does that segment's walk as well (it is that one
+  // element), and goes on while it keeps landing on long literals: one trip to memory per literal.
+  // (A walk of payload bytes lands on the tag of a long literal one time in a hundred: such chains die.)
+  if (w.last_size >= kSplitFollowMin) {
+    for (uint32_t hop = 0; hop < kSplitFollowMax && slot < kSplitCand; hop++) {
+      const uint32_t node = (pos / kSplitSeg) * kSplitCand + slot;
+      if (__hip_atomic_load(&p.ext[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSplitPending) {  // somebody has been here
+        open = kSplitNoNode;
+        break;
+      }
+      uint32_t b[5];
+#pragma unroll
+      for (uint32_t i = 0; i < 5; i++) b[i] = pos + i < p.n ? p.in[pos + i] : 0;
+      uint32_t L, size;
+      if (!decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), p.n - pos - 1, &L, &size)) break;
+      // (a block encoder's long literal; size >= the segment: the walk is this one element)
+      if ((b[0] & 3) != 0 || (b[0] >> 2) >= 62 || size < kSplitFollowMin) break;
+      const uint32_t p1 = pos + size;
+      __hip_atomic_store(&p.ob[node], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.ext[node], p1 == p.n ? kSplitEnd : p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      open = kSplitNoNode;
+      if (p1 >= p.n) break;
+      pos = p1;
+      slot = split_add(p, pos, &is_new, n_added);
+      if (is_new) open = (pos / kSplitSeg) * kSplitCand + slot;
+    }
+  }
+  if (open != kSplitNoNode && open / (kSplitCand * kSplitWg) == my_wg) open = kSplitNoNode;
+  return open;
+}
+
+// The walk of candidate (segment t, slot c, list entry e) against the segment's first walk (cp, f_*).  Returns the node
+// for the next round's queue: its exit's, or ITS OWN if it was not done within the budget (it is walked from its start
+// again there, without one), or kSplitNoNode.
+__device__ __forceinline__ uint32_t split_candidate(const SplitParams& p, const uint8_t* row, uint32_t t, uint32_t c, uint32_t e,
+                                                    uint64_t cp, uint32_t f_entry, uint32_t f_code, uint32_t f_obh,
+                                                    uint32_t budget, uint32_t my_wg, uint32_t* n_added) {
+  const uint32_t seg_lo = t * kSplitSeg;
+  const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
+  const uint32_t node = t * kSplitCand + c;
+  SplitWalk w{e & ~kSplitTrusted, 0, (e & kSplitTrusted) ? kSplitClean : 0, 0, false};
+  uint32_t code = kSplitPending;  // (pending: the walk reached the segment's end on its own)
+  bool hit = false;
+  split_walk_loop<2>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit, budget);
+  if (hit) {
+    // In step with the segment's first walk from here on: its exit, and what it put out behind this point (found by
+    // walking it again up to here, a few elements).  An exit that walk kept to itself -- it ended without its
+    // credit of native elements -- is no use: this walk goes on to the end on its own, and hands on what it finds.
+    if (f_code >= kSplitFirstCode || (f_obh >> 31)) {
+      SplitWalk r{f_entry, 0, 0, 0, false};
+      bool h2 = false;
+      split_walk_loop<0>(row, seg_lo, w.pos, p.n, &cp, &r, &h2, 0xffffffffu);
+      code = f_code;
+      w.out += (f_obh & 0x7fffffffu) - r.out;
+    } else {
+      if (budget != 0xffffffffu) return node;
+      split_walk_loop<0>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit, 0xffffffffu);
+    }
+  } else if (!w.bad && w.pos < seg_hi) {
+    return node;  // (the budget)
+  }
+  if (w.bad) code = kSplitBad;
+  const bool own_exit = code == kSplitPending;
+  if (own_exit) code = w.pos == p.n ? kSplitEnd : w.pos;
+  __hip_atomic_store(&p.ob[node], w.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p.ext[node], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool handed;
+  return own_exit ? split_hand_on(p, w, my_wg, &handed, n_added) : kSplitNoNode;
+}
+
+#ifdef SNAPPY_HIP_DEBUG  // phase timers of the bulk launch (100 MHz ticks summed over the waves): flags[3 .. 7]
+#define SPLIT_TICK(k)                                                                  \
+  do {                                                                                 \
+    const uint64_t now_ = __builtin_readcyclecounter() * 0 + wall_clock64();           \
+    if (threadIdx.x == 0) atomicAdd(&p.flags[3 + (k)], (uint32_t)(now_ - tick_));      \
+    tick_ = now_;                                                                      \
+  } while (0)
+#else
+#define SPLIT_TICK(k) do { } while (0)
+#endif
+
+// The bulk launch: every segment's first walk, and what those hand on inside the wave (see the head of this file).
+__global__ __launch_bounds__(kSplitWg) void split_bulk_kernel(SplitParams p) {
+#ifdef SNAPPY_HIP_DEBUG
+  uint64_t tick_ = wall_clock64();
+#endif
   const uint32_t s = blockIdx.x * kSplitWg + threadIdx.x;
   const uint32_t wg_lo = blockIdx.x * kSplitWg * kSplitSeg;
   uint8_t* const stage = s_split_dyn;
-  if (!p.first) {  // (uniform: one load)
-    if (!__hip_atomic_load(&p.dirty[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-  }
-  // (cleared BEFORE the lists are read: a candidate that arrives behind the look leaves the flag up for the next launch)
-  if (threadIdx.x == 0) __hip_atomic_store(&p.dirty[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool live = s < p.nseg;
   const uint32_t seg_lo = s * kSplitSeg;
   const uint32_t seg_hi = (s + 1) * kSplitSeg < p.n ? (s + 1) * kSplitSeg : p.n;
   const uint8_t* const row = stage + threadIdx.x * kSplitRow;
   uint32_t* const my_ent = p.ent + (size_t)s * kSplitCand;
   uint32_t* const my_ext = p.ext + (size_t)s * kSplitCand;
-  uint32_t* const my_ob = p.ob + (size_t)s * kSplitCand;
   split_stage(p, stage, wg_lo);
-  // the lane's first walk of this launch (in the first launch: the guess): its checkpoints, where it started, its exit
-  // code and output bytes, whether it handed its exit on
+  SPLIT_TICK(0);
+  uint32_t n_added = 0, done = 0;  // (done: the slots this launch has walked, or put on the queue)
+  // the first walk: from the segment's first byte, a guess, which is nobody's successor and has no slot (segment 0: the
+  // root, slot 0, and no guess)
   uint64_t cp = 0;
-  bool have_first = false, first_handed = false;
-  uint32_t first_entry = 0, first_code = kSplitPending, first_ob = 0;
-  uint32_t done = 0, n_added = 0;  // (done: the slots walked in this launch)
-  for (uint32_t it = 0; it < p.local_max; it++) {
-    uint32_t todo = 0;
-    uint32_t ent[kSplitCand + 1];
-    ent[kSplitCand] = seg_lo;  // bit kSplitCand: the guess, which is nobody's successor and has no slot
-    if (p.first && it == 0) {  // (nothing is listed yet but the root)
-      if (live && s != 0) todo |= 1u << kSplitCand;
-#pragma unroll
-      for (uint32_t c = 0; c < kSplitCand; c++) ent[c] = 0xffffffffu;
-      if (s == 0) ent[0] = kSplitTrusted, todo |= 1u;
-    } else {
-      // (all twelve loads in flight at once: one after the other they are twelve trips to the L2 a round)
-      uint32_t x[kSplitCand];
-#pragma unroll
-      for (uint32_t c = 0; c < kSplitCand; c++)
-        ent[c] = live ? __hip_atomic_load(&my_ent[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-#pragma unroll
-      for (uint32_t c = 0; c < kSplitCand; c++)
-        x[c] = live ? __hip_atomic_load(&my_ext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-      for (uint32_t c = 0; c < kSplitCand; c++)
-        if (ent[c] != 0xffffffffu && !((done >> c) & 1) && x[c] == kSplitPending) todo |= 1u << c;
+  uint32_t f_entry = seg_lo, f_code = kSplitBad, f_obh = 0;
+  {
+    uint32_t push = kSplitNoNode;
+    if (live) {
+      SplitWalk w{seg_lo, 0, s == 0 ? kSplitClean : 0, 0, false};
+      bool hit = false, handed = false;
+      split_walk_loop<1>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit, 0xffffffffu);
+      SPLIT_TICK(1);
+      f_code = w.bad ? kSplitBad : (w.pos == p.n ? kSplitEnd : w.pos);
+      if (s == 0) {
+        __hip_atomic_store(&p.ob[0], w.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.ext[0], f_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done |= 1u;
+      }
+      if (!w.bad) push = split_hand_on(p, w, blockIdx.x, &handed, &n_added);
+      f_obh = w.out | (handed ? 0x80000000u : 0u);
+      p.cp[s] = cp;
+      p.f_entry[s] = f_entry;
+      p.f_code[s] = f_code;
+      p.f_ob[s] = f_obh;
     }
-    if (!__ballot(todo != 0)) break;
-    for (uint32_t cc = 0; cc <= kSplitCand; cc++) {
-      const uint32_t c = cc == 0 ? kSplitCand : cc - 1;  // (the guess first)
-      if (!__ballot((todo >> c) & 1)) continue;
-      if ((todo >> c) & 1) {
-        uint32_t e = ent[kSplitCand];
+    SPLIT_TICK(2);
+    split_push(p, push);
+    SPLIT_TICK(3);
+  }
+  for (uint32_t it = 1; it <= p.local_max; it++) {
+    // (the lists are read: the lanes' entries and exits of the round before have arrived at the L2)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // (all twelve loads in flight at once: one after the other they are twelve trips to the L2 a round)
+    uint32_t ent[kSplitCand], x[kSplitCand], todo = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kSplitCand; k++) e = k == c ? ent[k] : e;
-        SplitWalk w{e & ~kSplitTrusted, 0, (e & kSplitTrusted) ? kSplitClean : 0, 0, false};
-        const uint32_t entry = w.pos;
-        uint32_t code = kSplitPending;  // (pending: the walk reached the segment's end on its own)
-        bool took_over = false, hit = false;
-        if (!have_first) {
-          split_walk_loop<1>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit);
+    for (uint32_t c = 0; c < kSplitCand; c++)
+      ent[c] = live ? __hip_atomic_load(&my_ent[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+#pragma unroll
+    for (uint32_t c = 0; c < kSplitCand; c++)
+      x[c] = live ? __hip_atomic_load(&my_ext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < kSplitCand; c++)
+      if (ent[c] != 0xffffffffu && !((done >> c) & 1) && x[c] == kSplitPending) todo |= 1u << c;
+    if (!__ballot(todo != 0)) break;
+    for (uint32_t c = 0; c < kSplitCand; c++) {
+      if (!__ballot((todo >> c) & 1)) continue;
+      uint32_t push = kSplitNoNode;
+      if ((todo >> c) & 1) {
+        if (it == p.local_max) {
+          push = s * kSplitCand + c;  // the last look: what is listed and not walked goes on the queue
         } else {
-          split_walk_loop<2>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit);
-          if (hit) {
-            // In step with the lane's first walk from here on: its exit, and what it put out behind this point (found by
-            // walking it again up to here, a few elements).  An exit that walk kept to itself -- it ended without its
-            // credit of native elements -- is no use: this walk goes on to the end on its own, and hands on what it finds.
-            if (first_code >= kSplitFirstCode || first_handed) {
-              SplitWalk r{first_entry, 0, 0, 0, false};
-              bool h2 = false;
-              split_walk_loop<0>(row, seg_lo, w.pos, p.n, &cp, &r, &h2);
-              code = first_code;
-              w.out += first_ob - r.out;
-              took_over = true;
-            } else {
-              split_walk_loop<0>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit);
-            }
-          }
-        }
-        if (w.bad) code = kSplitBad;
-        const bool own_exit = code == kSplitPending;
-        if (own_exit) code = w.pos == p.n ? kSplitEnd : w.pos;
-        if (c < kSplitCand) {
-          __hip_atomic_store(&my_ob[c], w.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&my_ext[c], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t e = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < kSplitCand; k++) e = k == c ? ent[k] : e;
+          push = split_candidate(p, row, s, c, e, cp, f_entry, f_code, f_obh, p.budget, blockIdx.x, &n_added);
         }
         done |= 1u << c;
-        bool handed_on = took_over;
-        if (own_exit && w.pos < p.n && w.clean >= kSplitClean) {
-          uint32_t pos = w.pos;
-          uint32_t slot = split_add(p, pos, &n_added);
-          handed_on = slot < kSplitCand;
-          // Follow-through.  Long literals back to back (incompressible blocks: one literal of 64 KiB each) are
-          // a chain that would be discovered ONE literal per round -- the segment a literal ends in learns the
-          // candidate from the walk of the segment the literal starts in.  So a walk that leaves its segment
-          // with a long literal and lands on another one does that segment's walk as well (it is that one
-          // element), and goes on while it keeps landing on long literals: one trip to memory per literal.
-          // (A walk of payload bytes lands on the tag of a long literal one time in a hundred: such chains die.)
-          if (w.last_size >= kSplitFollowMin) {
-            for (uint32_t hop = 0; hop < kSplitFollowMax && slot < kSplitCand; hop++) {
-              const uint32_t node = (pos / kSplitSeg) * kSplitCand + slot;
-              if (__hip_atomic_load(&p.ext[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kSplitPending) break;  // somebody has been here
-              uint32_t b[5];
+      }
+      split_push(p, push);
+    }
+  }
+  SPLIT_TICK(4);
+  for (int d = 32; d >= 1; d >>= 1) n_added += __shfl_xor(n_added, d, 64);
+  if (threadIdx.x == 0 && n_added) atomicAdd(&p.counters[0], n_added);
+}
+
+// A lane stages segment t by itself (row: its own 260 bytes of LDS), all its loads in flight at once.
+__device__ __forceinline__ void split_stage_row(const SplitParams& p, uint8_t* row, uint32_t t) {
+  const uint64_t g0 = (uint64_t)t * kSplitSeg;
+  uint32_t* const d = reinterpret_cast<uint32_t*>(row);
+  if (g0 + kSplitSeg + 16 <= p.n) {
+    uint4 v[16];
 #pragma unroll
-              for (uint32_t i = 0; i < 5; i++) b[i] = pos + i < p.n ? p.in[pos + i] : 0;
-              uint32_t L, size;
-              if (!decode_element_bf(b[0], b[1] | (b[2] << 8) | (b[3] << 16) | (b[4] << 24), p.n - pos - 1, &L, &size)) break;
-              // (a block encoder's long literal; size >= the segment: the walk is this one element)
-              if ((b[0] & 3) != 0 || (b[0] >> 2) >= 62 || size < kSplitFollowMin) break;
-              const uint32_t p1 = pos + size;
-              __hip_atomic_store(&p.ob[node], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(&p.ext[node], p1 == p.n ? kSplitEnd : p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (p1 >= p.n) break;
-              pos = p1;
-              slot = split_add(p, pos, &n_added);
-            }
-          }
-        }
-        if (!have_first) {
-          have_first = true;
-          first_entry = entry;
-          first_code = code;
-          first_ob = w.out;
-          first_handed = handed_on;
+    for (uint32_t k = 0; k < 16; k++) __builtin_memcpy(&v[k], p.in + g0 + k * 16, 16);
+    uint32_t x;
+    __builtin_memcpy(&x, p.in + g0 + kSplitSeg, 4);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) d[4 * k] = v[k].x, d[4 * k + 1] = v[k].y, d[4 * k + 2] = v[k].z, d[4 * k + 3] = v[k].w;
+    d[kSplitSeg / 4] = x;
+  } else {
+    for (uint32_t k = 0; k <= kSplitSeg / 4; k++) {
+      uint32_t x = 0;
+      for (uint32_t b = 0; b < 4; b++)
+        if (g0 + 4 * k + b < p.n) x |= (uint32_t)p.in[g0 + 4 * k + b] << (8 * b);
+      d[k] = x;
+    }
+  }
+}
+
+// A later round: the queue's nodes, a lane each; the lane stages its node's segment itself, and goes on along what the
+// walk hands on (the next node of ITS chain: repeated strings are a literal of kilobytes, a stretch of copies, a
+// literal ... -- a hop each, and nothing but the chain itself finds them), kSplitHops nodes at most.
+constexpr uint32_t kSplitHops = 16;
+__global__ __launch_bounds__(kSplitWg) void split_tail_kernel(SplitParams p) {
+  uint8_t* const row = s_split_dyn + threadIdx.x * kSplitRow;
+  const uint32_t n_items = min(__hip_atomic_load(p.q_in_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), p.q_cap);
+  uint32_t n_added = 0;
+  for (uint32_t base = blockIdx.x * kSplitWg; base < n_items; base += gridDim.x * kSplitWg) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t node = i < n_items ? p.q_in[i] : kSplitNoNode;
+    for (uint32_t hop = 0; hop < p.hops && __ballot(node != kSplitNoNode); hop++) {
+      uint32_t next = kSplitNoNode;
+      if (node != kSplitNoNode) {
+        const uint32_t t = node / kSplitCand, c = node % kSplitCand;
+        const uint32_t e = __hip_atomic_load(&p.ent[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (walked meanwhile: by a follow-through, by its wave's local rounds, as a duplicate of the queue)
+        if (__hip_atomic_load(&p.ext[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSplitPending && e != 0xffffffffu) {
+          split_stage_row(p, row, t);
+          next = split_candidate(p, row, t, c, e, p.cp[t], p.f_entry[t], p.f_code[t], p.f_ob[t], 0xffffffffu, 0xffffffffu, &n_added);
         }
       }
+      node = next;
     }
-    // (the lists are read again: the lanes' entries and exits of this round have arrived at the L2)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    split_push(p, node);
   }
   for (int d = 32; d >= 1; d >>= 1) n_added += __shfl_xor(n_added, d, 64);
   if (threadIdx.x == 0 && n_added) atomicAdd(&p.counters[0], n_added);
@@ -461,31 +591,44 @@ __global__ __launch_bounds__(256) void split_tile_scan_kernel(const uint32_t* v,
   }
 }
 
-// the last walk, along the real chain: which element starts at each 64 KiB boundary of the output
+// the last walk, along the real chain: which element starts at each 64 KiB boundary of the output.  One boundary in a
+// hundred and fifty segments: a LANE per boundary finds the segment whose elements cover it (out_at is sorted: the last
+// segment that starts at or below the boundary), stages that one segment and walks it from the real chain's entry.
+// (Round 4 walked every segment again, a wave per 64: 0.5 ms for a GiB.)
 __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
-  const uint32_t s = blockIdx.x * kSplitWg + threadIdx.x;
-  const uint32_t wg_lo = blockIdx.x * kSplitWg * kSplitSeg;
-  uint8_t* const stage = s_split_dyn;
-  const bool live = s < p.nseg;
-  const uint32_t seg_hi = (s + 1) * kSplitSeg < p.n ? (s + 1) * kSplitSeg : p.n;
-  uint32_t pos = live ? p.entry[s] : 0xffffffffu;
-  if (!__ballot(pos < seg_hi)) return;
-  split_stage(p, stage, wg_lo);
-  if (!live || pos >= seg_hi) return;
-  const uint8_t* const row = stage + threadIdx.x * kSplitRow;
+  uint8_t* const row = s_split_dyn + threadIdx.x * kSplitRow;
+  const uint32_t k = blockIdx.x * kSplitWg + threadIdx.x + 1;  // block 0 starts at the stream's first byte
+  if (k >= p.nblk) return;
+  const uint64_t want = (uint64_t)k << 16;
+  if (want >= p.out_at[p.nseg]) return;  // (the elements do not produce that much: the table kernel says so)
+  uint32_t lo = 0, hi = p.nseg;  // the last s with out_at[s] <= want (out_at[0] = 0; such an s puts out bytes: out_at[s + 1] > want)
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (p.out_at[mid] <= want) lo = mid;
+    else hi = mid;
+  }
+  const uint32_t s = lo;
+  uint32_t pos = p.entry[s];
+  const uint32_t seg_lo = s * kSplitSeg;
+  const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
+  if (pos >= seg_hi) {  // (cannot be: a segment that puts out bytes has an entry)
+    p.flags[1] = 1;
+    return;
+  }
+  split_stage_row(p, row, s);
   uint64_t op = p.out_at[s];
-  while (pos < seg_hi) {
+  while (pos < seg_hi && op < want) {
     uint32_t L, size;
     bool nat;
-    if (!split_element(row, pos - s * kSplitSeg, p.n - pos - 1, &L, &size, &nat)) {
+    if (!split_element(row, pos - seg_lo, p.n - pos - 1, &L, &size, &nat)) {
       p.flags[1] = 1;
       return;
     }
-    if ((op & 0xffffu) == 0 && (op >> 16) < p.nblk) p.blk_in[op >> 16] = pos;
-    else if (((op + L - 1) >> 16) != (op >> 16)) p.flags[2] = 1;  // crosses a 64 KiB boundary of the output
     op += L;
     pos += size;
   }
+  if (op == want) p.blk_in[k] = pos;  // (the element that starts the block -- in this segment or behind it)
+  else p.flags[2] = 1;                // an element crosses the boundary: a foreign encoder (or op < want: cannot be)
 }
 
 // the blocks as units of the block decoder, from where they start in the stream (blk_in[k], k >= 1; block 0 at 0)

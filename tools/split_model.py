@@ -1,7 +1,7 @@
 """CPU model of the raw-buffer splitter (nim-snappy_amd/csrc/split_kernels.h), segment by segment, the way the
-kernels do it: candidate entries per 256-byte segment, walks that hand their exits on (a wave's local rounds, walks that
-stop where they fall into step with an earlier one), follow-through of long literals, successor pointers, marking by
-pointer doubling.  tests/test_split_model.py checks that the marked
+kernels do it: candidate entries per 256-byte segment, walks that hand their exits on (the bulk launch's first walks and
+local rounds, walks that stop where they fall into step with the segment's first one, the queue of the tail rounds),
+follow-through of long literals, successor pointers, marking by pointer doubling.  tests/test_split_model.py checks that the marked
 entries are exactly the sequential parse's (decoder.nim:39-109) on the streams the GPU tests use.  Not the product:
 the product is the HIP code; this is its executable description."""
 
@@ -39,183 +39,234 @@ def native(tag):
     return not ((tag & 3) == 3 or ((tag & 3) == 0 and (tag >> 2) >= 62))
 
 
-WG, LOCAL_MAX, LAUNCHES_FIRST, LAUNCHES_LATER = 64, 66, 4, 4
+WG, LOCAL_MAX, BUDGET, HOPS, ROUNDS_BLIND, ROUNDS_MAX = 64, 4, 24, 16, 6, 12
 
 
-def split(s, max_looks=6, with_out=False, late=False):
-    """-> (entries {segment: entry position} of the marked chain, launches) or None (the kernels would fall back).
+def split(s, with_out=False, late=False, rounds=ROUNDS_BLIND):
+    """-> (entries {segment: entry position} of the marked chain, tail rounds that had work) or None (the chain is not
+    complete behind `rounds` tail rounds, or never: the kernels would try again with ROUNDS_MAX, then fall back).
     with_out: a third item, {segment: output bytes of the elements the marked walk of it covers}.
-    late: a candidate handed to a segment of ANOTHER wave is seen by that wave in the next launch only (the waves of a
-    launch run side by side; the model runs them one after the other, which is the other extreme).
+    late: what a wave hands to a segment of ANOTHER wave in the bulk launch is never seen by that wave's local rounds,
+    only by the queue (the waves of a launch run side by side; the model runs them one after the other, which is the
+    other extreme).
 
-    One launch of the walk kernel = every wave (64 segments, their 16 KiB staged in LDS) that has something new
-    (first launch: every wave; later: its dirty flag) runs LOCAL rounds until none of its segments has a candidate
-    that is not walked: a candidate handed to a segment of the same wave is walked in the next local round, without
-    a launch.  A segment's first walk of THIS launch leaves checkpoints (the first element start in each of its eight
-    32-byte blocks); a later walk that enters a block at its checkpoint has fallen into step with the first one: it
-    stops, and takes that walk's exit (which that walk has handed on already) and output bytes from there (found by
-    walking the first walk again up to the meeting point: a few elements).  If the first walk did not hand its exit on
-    (it ended without its credit of native elements), the walk goes on to the end on its own."""
+    The bulk launch: every segment's FIRST walk, from its first byte (a guess; segment 0: the root), which leaves
+    checkpoints (the first element start in each of its eight 32-byte blocks) and a summary; then a wave (64 segments)
+    walks what those handed to its own segments, in local rounds, with a budget of elements a walk: a walk that enters a
+    block at the first walk's checkpoint has fallen into step with it and takes over its exit and its output bytes
+    from there; what is not done within the budget, what is listed and not walked behind the last local round, and what
+    is handed to another wave goes on the queue.  A tail round: every queued node by a lane of its own, the same way
+    without a budget, and on along what it hands on, HOPS nodes at most; the rest onto the next round's queue."""
     n = len(s)
     nseg = (n + SEG - 1) // SEG
     nwg = (nseg + WG - 1) // WG
     ent = [[] for _ in range(nseg)]       # (pos) -- every listed candidate is trusted
     ext = [[] for _ in range(nseg)]
     ob = [[] for _ in range(nseg)]
+    foreign = [[] for _ in range(nseg)]   # added by another wave during the bulk launch
     ent[0].append(0)
     ext[0].append(PENDING)
     ob[0].append(0)
-    born = [[] for _ in range(nseg)]      # (launch, wave that added it)
-    born[0].append((-1, -1))
-    now = [0, -1]                         # the launch, the wave that is running
-    dirty = [False] * nwg
-    overflow = False
+    foreign[0].append(False)
+    first = {}                            # t -> (checkpoints {block: pos}, entry, exit code, output bytes, handed on)
+    state = {"overflow": False, "wg": None}
 
     def add(pos):
-        nonlocal overflow
+        """-> (node, is_new)"""
         t = pos // SEG
         if pos in ent[t]:
-            return t, ent[t].index(pos)
+            return (t, ent[t].index(pos)), False
         if len(ent[t]) >= CAND:
-            overflow = True
-            return None
+            state["overflow"] = True
+            return None, False
         ent[t].append(pos)
         ext[t].append(PENDING)
         ob[t].append(0)
-        born[t].append((now[0], now[1]))
-        dirty[t // WG] = True
-        return t, len(ent[t]) - 1
+        foreign[t].append(state["wg"] is not None and t // WG != state["wg"])
+        return (t, len(ent[t]) - 1), True
 
-    def hand_on(pos, clean, last):
-        """-> handed on (the exit is a candidate now, or was one)"""
+    def hand_on(pos, clean, last, my_wg):
+        """-> (handed on, the node that still has to be walked and is not one of wave my_wg's own, or None)"""
         if pos >= n or clean < CLEAN:
-            return False
-        node = add(pos)
+            return False, None
+        node, is_new = add(pos)
         if node is None:
-            return False
-        if last < FOLLOW_MIN:
-            return True
-        while node is not None:  # follow-through
-            t, c = node
-            if ext[t][c] != PENDING:
-                break
-            e = element(s, pos)
-            if e is None or (e[2] & 3) != 0 or (e[2] >> 2) >= 62 or e[1] < FOLLOW_MIN:
-                break
-            pos += e[1]
-            ob[t][c] = e[0]
-            ext[t][c] = END if pos == n else pos
-            if pos >= n:
-                break
-            node = add(pos)
-        return True
-
-    def launch(first_launch):
-        for w in range(nwg):
-            if not first_launch and not dirty[w]:
-                continue
-            dirty[w] = False
-            now[1] = w
-            segs = range(w * WG, min((w + 1) * WG, nseg))
-            # a segment's FIRST walk of this launch (the first launch: the guess) leaves checkpoints -- per 32-byte block,
-            # the first element start in it; a later walk that enters a block at its checkpoint is in step with it
-            first = {}                     # t -> [checkpoints {block: pos}, entry, exit code, output bytes, handed on]
-            walked = set()
-            for it in range(LOCAL_MAX):
-                todo = [(t, c) for t in segs for c in range(len(ent[t])) if ext[t][c] == PENDING and (t, c) not in walked
-                        and not (late and born[t][c][0] == now[0] and born[t][c][1] != w)]
-                if first_launch and it == 0:
-                    todo = [(t, None) for t in segs if t != 0] + todo  # the guesses (no slot, nobody's successor)
-                if not todo:
-                    if late and any(ext[t][c] == PENDING for t in segs for c in range(len(ent[t]))):
-                        dirty[w] = True   # (the flag its sender sets behind the wave's look at its lists)
+            return False, None
+        open_ = node if is_new else None
+        if last >= FOLLOW_MIN:
+            while node is not None:  # follow-through
+                t, c = node
+                if ext[t][c] != PENDING:
+                    open_ = None
                     break
-                for t, c in todo:
-                    hi = min((t + 1) * SEG, n)
-                    entry = t * SEG if c is None else ent[t][c]
-                    pos, out, clean, last = entry, 0, (0 if c is None else CLEAN), 0
-                    code, handed = None, False
-                    mode = 2 if t in first else 1
-                    cps = first[t][0] if t in first else {}
-                    blk_prev = None
-                    while pos < hi:
-                        blk = (pos - t * SEG) // 32
-                        if blk != blk_prev:
-                            blk_prev = blk
-                            if mode == 1:
-                                cps[blk] = pos
-                            elif mode == 2 and cps.get(blk) == pos:
-                                _, e0, x0, o0, h0 = first[t]
-                                if x0 in (END, BAD) or h0:
-                                    p2, o2 = e0, 0   # what the first walk put out up to here
-                                    while p2 < pos:
-                                        e = element(s, p2)
-                                        o2 += e[0]
-                                        p2 += e[1]
-                                    assert p2 == pos
-                                    code, out, handed = x0, out + o0 - o2, True
-                                    break
-                                mode = 0   # that walk kept its exit to itself: go on alone
-                        e = element(s, pos)
-                        if e is None:
-                            code = BAD
-                            break
-                        clean = clean + 1 if native(e[2]) else 0
-                        out += e[0]
-                        pos += e[1]
-                        last = e[1]
-                    if code is None:
-                        code = END if pos == n else pos
-                        handed = hand_on(pos, clean, last)
-                    if c is not None:
-                        ext[t][c] = code
-                        ob[t][c] = out
-                        walked.add((t, c))
-                    if t not in first:
-                        first[t] = [cps, entry, code, out, handed]
+                e = element(s, pos)
+                if e is None or (e[2] & 3) != 0 or (e[2] >> 2) >= 62 or e[1] < FOLLOW_MIN:
+                    break
+                pos += e[1]
+                ob[t][c] = e[0]
+                ext[t][c] = END if pos == n else pos
+                open_ = None
+                if pos >= n:
+                    break
+                node, is_new = add(pos)
+                if is_new:
+                    open_ = node
+        if open_ is not None and open_[0] // WG == my_wg:
+            open_ = None
+        return True, open_
 
-    launches = 0
-    for look in range(max_looks):
-        for r in range(LAUNCHES_FIRST if look == 0 else LAUNCHES_LATER):
-            now[0] = launches
-            launch(look == 0 and r == 0)
-            launches += 1
-        # successor pointers and the marking
-        ids = {(t, c): i for i, (t, c) in enumerate((t, c) for t in range(nseg) for c in range(len(ent[t])))}
-        keys = list(ids)
-        jump = []
-        for t, c in keys:
-            x = ext[t][c]
-            if x in (PENDING, END, BAD):
-                jump.append(x)
-            else:
-                tt = x // SEG
-                jump.append(ids[(tt, ent[tt].index(x))] if x in ent[tt] else PENDING)
-        reach = [False] * len(keys)
-        reach[0] = True
-        steps = 1
-        while (1 << (2 * steps)) < nseg + 1:
-            steps += 1
-        for _ in range(steps):  # four-fold jumps: a marked node marks 1, 2 and 3 hops of the current pointers
-            nj = list(jump)
-            for i, j in enumerate(jump):
-                mark = j >= 0 and reach[i]
-                for _hop in range(3):
-                    if j < 0:
-                        break
-                    if mark:
-                        reach[j] = True
-                    j = jump[j]
-                nj[i] = j
-            jump = nj
-        if jump[0] == END:
-            entries = {t: ent[t][c] for (t, c), i in ids.items() if reach[i]}
-            if with_out:
-                return entries, launches, {t: ob[t][c] for (t, c), i in ids.items() if reach[i]}
-            return entries, launches
-        if jump[0] == BAD or (overflow and look >= 1):
-            return None
-    return None
+    def walk(t, pos, clean, mode, budget, cps=None):
+        """-> (pos, out, clean, last, bad, hit); mode 1 fills cps"""
+        hi = min((t + 1) * SEG, n)
+        out, last, blk_prev = 0, 0, None
+        if mode == 2:
+            cps = first[t][0]
+        while pos < hi and budget != 0:
+            budget -= 1
+            blk = (pos - t * SEG) // 32
+            if blk != blk_prev:
+                blk_prev = blk
+                if mode == 1:
+                    cps[blk] = pos
+                elif mode == 2 and cps.get(blk) == pos:
+                    return pos, out, clean, last, False, True
+            e = element(s, pos)
+            if e is None:
+                return pos, out, clean, last, True, False
+            clean = clean + 1 if native(e[2]) else 0
+            out += e[0]
+            pos += e[1]
+            last = e[1]
+        return pos, out, clean, last, False, False
+
+    def candidate(t, c, budget, my_wg):
+        """-> the node for the next round's queue (its exit's, or its own), or None"""
+        hi = min((t + 1) * SEG, n)
+        pos, out, clean, last, bad, hit = walk(t, ent[t][c], CLEAN, 2, budget)
+        code = None
+        if hit:
+            _, e0, x0, o0, h0 = first[t]
+            if x0 in (END, BAD) or h0:
+                p2, o2 = e0, 0   # what the first walk put out up to here
+                while p2 < pos:
+                    e = element(s, p2)
+                    o2 += e[0]
+                    p2 += e[1]
+                assert p2 == pos
+                code, out = x0, out + o0 - o2
+            else:  # that walk kept its exit to itself: go on alone
+                if budget != -1:
+                    return (t, c)
+                p3, o3, clean, last, bad, _ = walk_from(t, pos, clean)
+                pos, out = p3, out + o3
+        elif not bad and pos < hi:
+            return (t, c)   # (the budget)
+        own = code is None and not bad
+        if bad:
+            code = BAD
+        if own:
+            code = END if pos == n else pos
+        ext[t][c] = code
+        ob[t][c] = out
+        return hand_on(pos, clean, last, my_wg)[1] if own else None
+
+    def walk_from(t, pos, clean):
+        hi = min((t + 1) * SEG, n)
+        out, last = 0, 0
+        while pos < hi:
+            e = element(s, pos)
+            if e is None:
+                return pos, out, clean, last, True, False
+            clean = clean + 1 if native(e[2]) else 0
+            out += e[0]
+            pos += e[1]
+            last = e[1]
+        return pos, out, clean, last, False, False
+
+    # the bulk launch
+    queue = []
+    for w in range(nwg):
+        state["wg"] = w
+        segs = range(w * WG, min((w + 1) * WG, nseg))
+        queued = set()
+        for t in segs:
+            cps = {}
+            pos, out, clean, last, bad, _ = walk(t, t * SEG, CLEAN if t == 0 else 0, 1, -1, cps)
+            code = BAD if bad else (END if pos == n else pos)
+            if t == 0:
+                ext[0][0], ob[0][0] = code, out
+            handed, open_ = (False, None) if bad else hand_on(pos, clean, last, w)
+            first[t] = (cps, t * SEG, code, out, handed)
+            if open_ is not None:
+                queue.append(open_)
+        for it in range(1, LOCAL_MAX + 1):
+            todo = [(t, c) for t in segs for c in range(len(ent[t])) if ext[t][c] == PENDING and (t, c) not in queued
+                    and not (late and foreign[t][c])]
+            if not todo:
+                break
+            for t, c in todo:
+                if it == LOCAL_MAX:
+                    queue.append((t, c))   # the last look: what is listed and not walked goes on the queue
+                    continue
+                nxt = candidate(t, c, BUDGET, w)
+                if nxt == (t, c):
+                    queued.add(nxt)
+                if nxt is not None:
+                    queue.append(nxt)
+    state["wg"] = None
+    # the tail rounds
+    worked = 0
+    for r in range(rounds):
+        if not queue:
+            break
+        worked += 1
+        nxt_queue = []
+        for node in queue:
+            for hop in range(HOPS):
+                t, c = node
+                if ext[t][c] != PENDING:
+                    node = None
+                    break
+                node = candidate(t, c, -1, None)
+                if node is None:
+                    break
+            if node is not None:
+                nxt_queue.append(node)
+        queue = nxt_queue
+    # successor pointers and the marking
+    ids = {(t, c): i for i, (t, c) in enumerate((t, c) for t in range(nseg) for c in range(len(ent[t])))}
+    keys = list(ids)
+    jump = []
+    for t, c in keys:
+        x = ext[t][c]
+        if x in (PENDING, END, BAD):
+            jump.append(x)
+        else:
+            tt = x // SEG
+            jump.append(ids[(tt, ent[tt].index(x))] if x in ent[tt] else PENDING)
+    reach = [False] * len(keys)
+    reach[0] = True
+    steps = 1
+    while (1 << (2 * steps)) < nseg + 1:
+        steps += 1
+    for _ in range(steps):  # four-fold jumps: a marked node marks 1, 2 and 3 hops of the current pointers
+        nj = list(jump)
+        for i, j in enumerate(jump):
+            mark = j >= 0 and reach[i]
+            for _hop in range(3):
+                if j < 0:
+                    break
+                if mark:
+                    reach[j] = True
+                j = jump[j]
+            nj[i] = j
+        jump = nj
+    if jump[0] != END:
+        return None
+    entries = {t: ent[t][c] for (t, c), i in ids.items() if reach[i]}
+    if with_out:
+        return entries, worked, {t: ob[t][c] for (t, c), i in ids.items() if reach[i]}
+    return entries, worked
 
 
 def sequential_entries(s):
