@@ -1832,21 +1832,21 @@ int decode_host(snappy_hip_ctx* c, const uint8_t* in, size_t n, const std::vecto
 // (the walk saw the whole stream: its verdict stands), or -1: not applicable (the chain is not complete within the
 // looks, an invalid or foreign element lies on it, a candidate list overflowed, an element straddles a block
 // boundary).
-// looks == false: everything is enqueued without a look from the host -- the bulk launch, six tail rounds (one with an
+// looks == false: everything is enqueued without a look from the host -- the bulk launch, four tail rounds (one with an
 // empty queue is a load per wave), the marking, the placement; the verdict kernels note whether the root's chain
 // reached the stream's end, and the caller, who looks once behind the decode, comes back with looks == true if it did
 // not: the procedure from its start, the host reading every round's queue length (up to twelve rounds) before it marks.
 int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags, uint64_t len, size_t nblk,
                       uint32_t* d_blk, hipStream_t s, uint32_t* d_ol, uint32_t* d_bad, const uint64_t** d_total,
                       const uint32_t** d_flags, bool looks) {
-  constexpr uint32_t kRoundsBlind = 6;
+  constexpr uint32_t kRoundsBlind = 4;
   const uint32_t nseg = (n_tags + kSplitSeg - 1) / kSplitSeg;
   const uint32_t nwg = (nseg + kSplitWg - 1) / kSplitWg;  // (the bulk launch: one wave and 16 KiB of staged stream each)
   const size_t nodes = (size_t)nseg * kSplitCand;
   void* base;
   // per node: ent, ext, ob, two jump tables (4 bytes each; the queues until the marking), reach (1); per segment: entry,
   // outb (4), out_at (8), the first walk's checkpoints (8), entry, exit, output bytes (4)
-  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 36 + 8 + 64 + 64, &base);
+  int st = ws_get(c, 13, nodes * 21 + (size_t)nseg * 36 + (nodes / 256 + 1) * 4 + 8 + 64 + 64 + 8, &base);
   if (st) return st;
   uint8_t* q = (uint8_t*)base;
   uint64_t* out_at = (uint64_t*)q;
@@ -1876,6 +1876,8 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   q += 64;
   uint32_t* flags = (uint32_t*)q;
   q += 32;
+  uint32_t* blk_any = (uint32_t*)q;  // per 256 ids of the marking: a node among them (split_succ_kernel)
+  q += (nodes / 256 + 1) * 4;
   uint8_t* reach = q;
   {  // ent and ext: no candidates but the root, nothing walked; counters, flags; block starts, lengths, verdict
     const uint32_t ig = (uint32_t)((nodes * 2 + 255) / 256 < 1024 ? (nodes * 2 + 255) / 256 : 1024);
@@ -1902,13 +1904,12 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   sp.blk_in = d_blk;
   sp.nblk = (uint32_t)nblk;
   sp.bad = d_bad;
-  sp.local_max = kSplitLocalMax;
   sp.budget = kSplitBudget;
   sp.hops = kSplitHops;
-  if (const char* e = dbg_env("SNAPPY_HIP_SPLIT_KNOBS")) {  // DEBUG: "local rounds,budget,hops"
-    unsigned a = kSplitLocalMax, b = kSplitBudget, h = kSplitHops;
-    sscanf(e, "%u,%u,%u", &a, &b, &h);
-    sp.local_max = a, sp.budget = b, sp.hops = h;
+  if (const char* e = dbg_env("SNAPPY_HIP_SPLIT_KNOBS")) {  // DEBUG: "budget,hops"
+    unsigned b = kSplitBudget, h = kSplitHops;
+    sscanf(e, "%u,%u", &b, &h);
+    sp.budget = b, sp.hops = h;
   }
   const uint32_t grid = (nseg + 255) / 256;
   const uint32_t ngrid = (uint32_t)((nodes + 255) / 256);
@@ -1925,7 +1926,7 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     uint32_t h[8];
     HIP_TRY(hipMemcpyAsync(h, flags, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    fprintf(stderr, "SPLIT bulk, us per wave: stage %.1f first walk %.1f hand on + summary %.1f push %.1f local rounds %.1f (%u waves)\n",
+    fprintf(stderr, "SPLIT bulk, us per wave: stage %.1f first walk %.1f hand on + summary %.1f second walk %.1f push %.1f (%u waves)\n",
             h[3] / 100.0 / nwg, h[4] / 100.0 / nwg, h[5] / 100.0 / nwg, h[6] / 100.0 / nwg, h[7] / 100.0 / nwg, nwg);
     HIP_TRY(hipMemsetAsync(flags + 3, 0, 20, s));
   }
@@ -1949,10 +1950,11 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
   // is the real chain complete?  mark what the root reaches; its last pointer tells
   int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
   while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
-  LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach);
+  LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach, blk_any);
   int cur = 0;
   for (int k = 0; k < steps; k++, cur ^= 1)
-    LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach);
+    LAUNCH(split_double_kernel, dim3(ngrid), dim3(256), 0, s, (uint32_t)nodes, (const uint32_t*)jump[cur], jump[cur ^ 1], reach,
+           (const uint32_t*)blk_any);
   HIP_TRY(hipGetLastError());
   if (looks) {
     uint32_t h_root = 0, h_cnt[2] = {0, 0};

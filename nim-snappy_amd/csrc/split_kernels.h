@@ -76,7 +76,7 @@ struct SplitParams {
   uint32_t* q_out;
   uint32_t* q_out_count;
   uint32_t q_cap;
-  uint32_t local_max, budget, hops;  // kSplitLocalMax, kSplitBudget, kSplitHops (DEBUG builds: others, for measurements)
+  uint32_t budget, hops;  // kSplitBudget, kSplitHops (DEBUG builds: others, for measurements)
   // after the marking
   uint32_t* entry;        // [nseg] the entry of the real chain (all ones: it passes over the segment)
   uint32_t* outb;         // [nseg] output bytes of the elements that start in the segment
@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint
 constexpr uint32_t kSplitWg = 64;
 constexpr uint32_t kSplitRow = kSplitSeg + 4;
 constexpr uint32_t kSplitStage = kSplitWg * kSplitRow;  // 16 640 bytes: 13 pieces of LDS, nine waves a CU
-constexpr uint32_t kSplitLocalMax = 4;    // rounds of the bulk launch: the first walks, then what they hand on inside the wave
-constexpr uint32_t kSplitBudget = 24;     // elements a local walk may take (most meet the first walk within a dozen)
+constexpr uint32_t kSplitBudget = 24;     // elements a second walk of the bulk launch may take (most meet the first walk within a dozen)
 constexpr uint32_t kSplitMaxRounds = 13;  // tail launches at most (their queue lengths live in counters[2 .. 15])
 constexpr uint32_t kSplitNoNode = 0xffffffffu;
 extern __shared__ __attribute__((aligned(16))) uint8_t s_split_dyn[];
@@ -186,10 +185,15 @@ __device__ __forceinline__ void split_stage(const SplitParams& p, uint8_t* stage
 
 
 // `pos` becomes a (trusted) candidate of the segment it lies in, if it is not one already; the slot, or kSplitCand.
+// Slot 0 is not given out here: it is the segment's own -- what the first walk of the segment before hands to it inside a
+// wave of the bulk launch, written by the lane of the segment itself without an atomic (segment 0: the root).  If that
+// entry is this position it is found (behind the bulk launch always; during it, perhaps not yet: then the position is
+// listed twice, and both nodes are walked -- the marking takes either).
 __device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos, bool* is_new, uint32_t* n_added) {
   uint32_t* e = p.ent + (pos / kSplitSeg) * kSplitCand;
   *is_new = false;
-  for (uint32_t c = 0; c < kSplitCand; c++) {
+  if (__hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (pos | kSplitTrusted)) return 0;
+  for (uint32_t c = 1; c < kSplitCand; c++) {
     const uint32_t old = atomicCAS(&e[c], 0xffffffffu, pos | kSplitTrusted);
     if (old == 0xffffffffu) {
       *is_new = true;
@@ -214,6 +218,27 @@ __device__ __forceinline__ void split_push(const SplitParams& p, uint32_t node) 
     const uint32_t i = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
     if (i < p.q_cap) p.q_out[i] = node;
     else p.counters[1] = 1;  // (what does not fit is lost: the chain may be incomplete, like with a list that overflowed)
+  }
+}
+
+__device__ __forceinline__ void split_push2(const SplitParams& p, uint32_t a, uint32_t b) {
+  const uint64_t ma = __ballot(a != kSplitNoNode), mb = __ballot(b != kSplitNoNode);
+  if (!(ma | mb)) return;
+  const uint32_t na = (uint32_t)__builtin_popcountll(ma), nb = (uint32_t)__builtin_popcountll(mb);
+  uint32_t base = 0;
+  const uint32_t lane = threadIdx.x & 63;
+  if (lane == 0) base = atomicAdd(p.q_out_count, na + nb);
+  base = __shfl(base, 0, 64);
+  const uint64_t below = (1ull << lane) - 1;
+  if (a != kSplitNoNode) {
+    const uint32_t i = base + (uint32_t)__builtin_popcountll(ma & below);
+    if (i < p.q_cap) p.q_out[i] = a;
+    else p.counters[1] = 1;
+  }
+  if (b != kSplitNoNode) {
+    const uint32_t i = base + na + (uint32_t)__builtin_popcountll(mb & below);
+    if (i < p.q_cap) p.q_out[i] = b;
+    else p.counters[1] = 1;
   }
 }
 
@@ -348,7 +373,7 @@ __device__ __forceinline__ uint32_t split_candidate(const SplitParams& p, const 
 #ifdef SNAPPY_HIP_DEBUG  // phase timers of the bulk launch (100 MHz ticks summed over the waves): flags[3 .. 7]
 #define SPLIT_TICK(k)                                                                  \
   do {                                                                                 \
-    const uint64_t now_ = __builtin_readcyclecounter() * 0 + wall_clock64();           \
+    const uint64_t now_ = wall_clock64();                                              \
     if (threadIdx.x == 0) atomicAdd(&p.flags[3 + (k)], (uint32_t)(now_ - tick_));      \
     tick_ = now_;                                                                      \
   } while (0)
@@ -356,7 +381,12 @@ __device__ __forceinline__ uint32_t split_candidate(const SplitParams& p, const 
 #define SPLIT_TICK(k) do { } while (0)
 #endif
 
-// The bulk launch: every segment's first walk, and what those hand on inside the wave (see the head of this file).
+// The bulk launch: every segment's first walk, and the walk of what the first walk of the segment before hands to it
+// (see the head of this file).  A wave's trips to memory are what it takes: its stream bytes, one atomic for the exits
+// that leave the wave or skip a segment, one for the exits of second walks that did not meet the first, one for the
+// queue -- the hand-over from a segment to the next inside the wave is a shuffle, and that candidate is slot 0 of the
+// segment's list, written by the segment's own lane.  (With every hand-over a compare-and-swap and every look at a
+// list a load, a wave made ten trips one behind the other: 85 us, 24 of them walking.)
 __global__ __launch_bounds__(kSplitWg) void split_bulk_kernel(SplitParams p) {
 #ifdef SNAPPY_HIP_DEBUG
   uint64_t tick_ = wall_clock64();
@@ -368,71 +398,47 @@ __global__ __launch_bounds__(kSplitWg) void split_bulk_kernel(SplitParams p) {
   const uint32_t seg_lo = s * kSplitSeg;
   const uint32_t seg_hi = (s + 1) * kSplitSeg < p.n ? (s + 1) * kSplitSeg : p.n;
   const uint8_t* const row = stage + threadIdx.x * kSplitRow;
-  uint32_t* const my_ent = p.ent + (size_t)s * kSplitCand;
-  uint32_t* const my_ext = p.ext + (size_t)s * kSplitCand;
   split_stage(p, stage, wg_lo);
   SPLIT_TICK(0);
-  uint32_t n_added = 0, done = 0;  // (done: the slots this launch has walked, or put on the queue)
+  uint32_t n_added = 0;
   // the first walk: from the segment's first byte, a guess, which is nobody's successor and has no slot (segment 0: the
   // root, slot 0, and no guess)
   uint64_t cp = 0;
-  uint32_t f_entry = seg_lo, f_code = kSplitBad, f_obh = 0;
-  {
-    uint32_t push = kSplitNoNode;
-    if (live) {
-      SplitWalk w{seg_lo, 0, s == 0 ? kSplitClean : 0, 0, false};
-      bool hit = false, handed = false;
-      split_walk_loop<1>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit, 0xffffffffu);
-      SPLIT_TICK(1);
-      f_code = w.bad ? kSplitBad : (w.pos == p.n ? kSplitEnd : w.pos);
-      if (s == 0) {
-        __hip_atomic_store(&p.ob[0], w.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.ext[0], f_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        done |= 1u;
-      }
-      if (!w.bad) push = split_hand_on(p, w, blockIdx.x, &handed, &n_added);
-      f_obh = w.out | (handed ? 0x80000000u : 0u);
-      p.cp[s] = cp;
-      p.f_entry[s] = f_entry;
-      p.f_code[s] = f_code;
-      p.f_ob[s] = f_obh;
+  uint32_t f_code = kSplitBad, f_obh = 0, push_a = kSplitNoNode, push_b = kSplitNoNode;
+  uint32_t direct = 0xffffffffu;  // the exit, if it goes to the next segment by shuffle
+  if (live) {
+    SplitWalk w{seg_lo, 0, s == 0 ? kSplitClean : 0, 0, false};
+    bool hit = false, handed = false;
+    split_walk_loop<1>(row, seg_lo, seg_hi, p.n, &cp, &w, &hit, 0xffffffffu);
+    SPLIT_TICK(1);
+    f_code = w.bad ? kSplitBad : (w.pos == p.n ? kSplitEnd : w.pos);
+    if (s == 0) {
+      __hip_atomic_store(&p.ob[0], w.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&p.ext[0], f_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    SPLIT_TICK(2);
-    split_push(p, push);
-    SPLIT_TICK(3);
-  }
-  for (uint32_t it = 1; it <= p.local_max; it++) {
-    // (the lists are read: the lanes' entries and exits of the round before have arrived at the L2)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    // (all twelve loads in flight at once: one after the other they are twelve trips to the L2 a round)
-    uint32_t ent[kSplitCand], x[kSplitCand], todo = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < kSplitCand; c++)
-      ent[c] = live ? __hip_atomic_load(&my_ent[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-#pragma unroll
-    for (uint32_t c = 0; c < kSplitCand; c++)
-      x[c] = live ? __hip_atomic_load(&my_ext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-    for (uint32_t c = 0; c < kSplitCand; c++)
-      if (ent[c] != 0xffffffffu && !((done >> c) & 1) && x[c] == kSplitPending) todo |= 1u << c;
-    if (!__ballot(todo != 0)) break;
-    for (uint32_t c = 0; c < kSplitCand; c++) {
-      if (!__ballot((todo >> c) & 1)) continue;
-      uint32_t push = kSplitNoNode;
-      if ((todo >> c) & 1) {
-        if (it == p.local_max) {
-          push = s * kSplitCand + c;  // the last look: what is listed and not walked goes on the queue
-        } else {
-          uint32_t e = 0;
-#pragma unroll
-          for (uint32_t k = 0; k < kSplitCand; k++) e = k == c ? ent[k] : e;
-          push = split_candidate(p, row, s, c, e, cp, f_entry, f_code, f_obh, p.budget, blockIdx.x, &n_added);
-        }
-        done |= 1u << c;
+    if (!w.bad && w.pos < p.n && w.clean >= kSplitClean) {
+      if (threadIdx.x + 1 < kSplitWg && w.pos < seg_hi + kSplitSeg && w.last_size < kSplitFollowMin) {
+        direct = w.pos;
+        handed = true;
+      } else {
+        push_a = split_hand_on(p, w, 0xffffffffu, &handed, &n_added);
       }
-      split_push(p, push);
     }
+    f_obh = w.out | (handed ? 0x80000000u : 0u);
+    p.cp[s] = cp;
+    p.f_entry[s] = seg_lo;
+    p.f_code[s] = f_code;
+    p.f_ob[s] = f_obh;
   }
+  SPLIT_TICK(2);
+  // the second walk: what the segment before handed over
+  const uint32_t cand = __shfl_up(direct, 1, 64);
+  if (live && threadIdx.x != 0 && cand != 0xffffffffu) {
+    __hip_atomic_store(&p.ent[(size_t)s * kSplitCand], cand | kSplitTrusted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    push_b = split_candidate(p, row, s, 0, cand | kSplitTrusted, cp, seg_lo, f_code, f_obh, p.budget, 0xffffffffu, &n_added);
+  }
+  SPLIT_TICK(3);
+  split_push2(p, push_a, push_b);
   SPLIT_TICK(4);
   for (int d = 32; d >= 1; d >>= 1) n_added += __shfl_xor(n_added, d, 64);
   if (threadIdx.x == 0 && n_added) atomicAdd(&p.counters[0], n_added);
@@ -491,30 +497,42 @@ __global__ __launch_bounds__(kSplitWg) void split_tail_kernel(SplitParams p) {
   if (threadIdx.x == 0 && n_added) atomicAdd(&p.counters[0], n_added);
 }
 
-// successor of every node, and the root's mark
-__global__ __launch_bounds__(256) void split_succ_kernel(SplitParams p, uint32_t* jump, uint8_t* reach) {
-  const uint32_t node = blockIdx.x * 256 + threadIdx.x;
-  if (node >= p.nseg * kSplitCand) return;
-  uint32_t j = kSplitPending;
-  const uint32_t x = p.ext[node];
-  if (p.ent[node] == 0xffffffffu) {
-    j = kSplitPending;
-  } else if (x >= kSplitFirstCode) {
-    j = x;
-  } else {
-    const uint32_t t = x / kSplitSeg;
-    for (uint32_t c = 0; c < kSplitCand; c++)
-      if (p.ent[t * kSplitCand + c] == (x | kSplitTrusted)) j = t * kSplitCand + c;  // (what is handed on is trusted)
+// successor of every node, and the root's mark.  The marking's arrays are SLOT-major (id = slot * nseg + segment: the
+// root is id 0): most segments list one or two candidates, so the ids of slots 2 .. 5 are nearly all empty, whole
+// 256-id blocks of them -- any[block] says which blocks hold a node at all, and a step of the pointer jumping leaves a
+// block without one after one load (segment-major, every step streamed all six slots of every segment: 0.45 ms of the
+// 1 GiB buffer's 0.5 ms look).
+__global__ __launch_bounds__(256) void split_succ_kernel(SplitParams p, uint32_t* jump, uint8_t* reach, uint32_t* any) {
+  const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  bool listed = false;
+  if (id < p.nseg * kSplitCand) {
+    const uint32_t c = id / p.nseg, s = id - c * p.nseg, node = s * kSplitCand + c;
+    uint32_t j = kSplitPending;
+    const uint32_t x = p.ext[node];
+    listed = p.ent[node] != 0xffffffffu;
+    if (!listed) {
+      j = kSplitPending;
+    } else if (x >= kSplitFirstCode) {
+      j = x;
+    } else {
+      const uint32_t t = x / kSplitSeg;
+      for (uint32_t k = 0; k < kSplitCand; k++)
+        if (p.ent[t * kSplitCand + k] == (x | kSplitTrusted)) j = k * p.nseg + t;  // (what is handed on is trusted)
+    }
+    jump[id] = j;
+    reach[id] = id == 0 ? 1 : 0;
   }
-  jump[node] = j;
-  reach[node] = node == 0 ? 1 : 0;
+  const int some = __syncthreads_or(listed);
+  if (threadIdx.x == 0) any[blockIdx.x] = (uint32_t)some;
 }
 
 // one step of the pointer jumping, four-fold (half the launches of doubling): a marked node marks the three
 // nodes its pointer leads to in one, two and three hops, every pointer then shows four times as far.  (Before
 // step k the marked nodes are those less than 4^k hops from the root; they mark 4^k, 2*4^k, 3*4^k further.)
+// (A block without a node is never read: only a node is anybody's successor.)
 __global__ __launch_bounds__(256) void split_double_kernel(uint32_t n_nodes, const uint32_t* jump_in, uint32_t* jump_out,
-                                                           uint8_t* reach) {
+                                                           uint8_t* reach, const uint32_t* any) {
+  if (!any[blockIdx.x]) return;
   const uint32_t node = blockIdx.x * 256 + threadIdx.x;
   if (node >= n_nodes) return;
   uint32_t j = jump_in[node];
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(256) void split_select_kernel(SplitParams p, const 
   if (s >= p.nseg) return;
   uint32_t e = 0xffffffffu, o = 0;
   for (uint32_t c = 0; c < kSplitCand && r == kSplitEnd; c++)
-    if (reach[s * kSplitCand + c]) {
+    if (reach[c * p.nseg + s]) {  // (slot-major: split_succ_kernel)
       e = p.ent[s * kSplitCand + c] & ~kSplitTrusted;
       o = p.ob[s * kSplitCand + c];
     }

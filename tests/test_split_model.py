@@ -31,11 +31,10 @@ def _streams(orc):
 def test_marked_chain_is_the_sequential_parse(orc):
     for i, s in enumerate(_streams(orc)):
         want = sm.sequential_entries(s)
-        for late in (False, True):
-            got = sm.split(s, with_out=True, late=late)
-            assert want is not None and got is not None, (i, late)  # (complete within the rounds enqueued without a look)
-            assert got[0] == want, (i, late, got[1])
-            assert got[2] == sm.sequential_out(s), (i, late)  # (what the prefix sum over the marked walks places the segments by)
+        got = sm.split(s, with_out=True)
+        assert want is not None and got is not None, i  # (complete within the rounds enqueued without a look)
+        assert got[0] == want, (i, got[1])
+        assert got[2] == sm.sequential_out(s), i  # (what the prefix sum over the marked walks places the segments by)
 
 
 def test_a_damaged_stream_is_refused_or_right(orc):

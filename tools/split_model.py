@@ -39,50 +39,44 @@ def native(tag):
     return not ((tag & 3) == 3 or ((tag & 3) == 0 and (tag >> 2) >= 62))
 
 
-WG, LOCAL_MAX, BUDGET, HOPS, ROUNDS_BLIND, ROUNDS_MAX = 64, 4, 24, 16, 6, 12
+WG, BUDGET, HOPS, ROUNDS_BLIND, ROUNDS_MAX = 64, 24, 16, 4, 12
 
 
-def split(s, with_out=False, late=False, rounds=ROUNDS_BLIND):
+def split(s, with_out=False, rounds=ROUNDS_BLIND):
     """-> (entries {segment: entry position} of the marked chain, tail rounds that had work) or None (the chain is not
     complete behind `rounds` tail rounds, or never: the kernels would try again with ROUNDS_MAX, then fall back).
     with_out: a third item, {segment: output bytes of the elements the marked walk of it covers}.
-    late: what a wave hands to a segment of ANOTHER wave in the bulk launch is never seen by that wave's local rounds,
-    only by the queue (the waves of a launch run side by side; the model runs them one after the other, which is the
-    other extreme).
 
     The bulk launch: every segment's FIRST walk, from its first byte (a guess; segment 0: the root), which leaves
-    checkpoints (the first element start in each of its eight 32-byte blocks) and a summary; then a wave (64 segments)
-    walks what those handed to its own segments, in local rounds, with a budget of elements a walk: a walk that enters a
+    checkpoints (the first element start in each of its eight 32-byte blocks) and a summary; an exit into the next
+    segment of the same wave (64 segments) is walked there at once, with a budget of elements: a walk that enters a
     block at the first walk's checkpoint has fallen into step with it and takes over its exit and its output bytes
-    from there; what is not done within the budget, what is listed and not walked behind the last local round, and what
-    is handed to another wave goes on the queue.  A tail round: every queued node by a lane of its own, the same way
-    without a budget, and on along what it hands on, HOPS nodes at most; the rest onto the next round's queue."""
+    from there; what is not done within the budget, and every other exit, goes on the queue.  A tail round: every
+    queued node by a lane of its own, the same way without a budget, and on along what it hands on, HOPS nodes at most;
+    the rest onto the next round's queue."""
     n = len(s)
     nseg = (n + SEG - 1) // SEG
     nwg = (nseg + WG - 1) // WG
-    ent = [[] for _ in range(nseg)]       # (pos) -- every listed candidate is trusted
-    ext = [[] for _ in range(nseg)]
-    ob = [[] for _ in range(nseg)]
-    foreign = [[] for _ in range(nseg)]   # added by another wave during the bulk launch
-    ent[0].append(0)
-    ext[0].append(PENDING)
-    ob[0].append(0)
-    foreign[0].append(False)
+    # per segment: the listed candidates (every one is trusted); slot 0 is the segment's own (None: empty) -- the root's
+    # in segment 0, else what the first walk of the segment before hands over inside a wave of the bulk launch
+    ent = [[None] for _ in range(nseg)]
+    ext = [[PENDING] for _ in range(nseg)]
+    ob = [[0] for _ in range(nseg)]
+    ent[0][0] = 0
     first = {}                            # t -> (checkpoints {block: pos}, entry, exit code, output bytes, handed on)
-    state = {"overflow": False, "wg": None}
+    state = {"overflow": False}
 
     def add(pos):
         """-> (node, is_new)"""
         t = pos // SEG
         if pos in ent[t]:
             return (t, ent[t].index(pos)), False
-        if len(ent[t]) >= CAND:
+        if len(ent[t]) >= CAND:  # (slot 0 is not given out here)
             state["overflow"] = True
             return None, False
         ent[t].append(pos)
         ext[t].append(PENDING)
         ob[t].append(0)
-        foreign[t].append(state["wg"] is not None and t // WG != state["wg"])
         return (t, len(ent[t]) - 1), True
 
     def hand_on(pos, clean, last, my_wg):
@@ -183,37 +177,35 @@ def split(s, with_out=False, late=False, rounds=ROUNDS_BLIND):
             last = e[1]
         return pos, out, clean, last, False, False
 
-    # the bulk launch
+    # the bulk launch: the first walks; a first walk's exit into the NEXT segment of the same wave goes there by shuffle
+    # and is slot 0 of that segment's list (written by the segment's own lane), walked at once, with the budget; every
+    # other exit is listed by compare-and-swap (slots 1 .. 5) and goes on the queue
     queue = []
     for w in range(nwg):
-        state["wg"] = w
         segs = range(w * WG, min((w + 1) * WG, nseg))
-        queued = set()
+        direct = {}
         for t in segs:
             cps = {}
             pos, out, clean, last, bad, _ = walk(t, t * SEG, CLEAN if t == 0 else 0, 1, -1, cps)
             code = BAD if bad else (END if pos == n else pos)
             if t == 0:
                 ext[0][0], ob[0][0] = code, out
-            handed, open_ = (False, None) if bad else hand_on(pos, clean, last, w)
+            handed = False
+            if not bad and pos < n and clean >= CLEAN:
+                if t + 1 in segs and pos < min((t + 1) * SEG, n) + SEG and last < FOLLOW_MIN:
+                    direct[t + 1] = pos
+                    handed = True
+                else:
+                    handed, open_ = hand_on(pos, clean, last, None)
+                    if open_ is not None:
+                        queue.append(open_)
             first[t] = (cps, t * SEG, code, out, handed)
-            if open_ is not None:
-                queue.append(open_)
-        for it in range(1, LOCAL_MAX + 1):
-            todo = [(t, c) for t in segs for c in range(len(ent[t])) if ext[t][c] == PENDING and (t, c) not in queued
-                    and not (late and foreign[t][c])]
-            if not todo:
-                break
-            for t, c in todo:
-                if it == LOCAL_MAX:
-                    queue.append((t, c))   # the last look: what is listed and not walked goes on the queue
-                    continue
-                nxt = candidate(t, c, BUDGET, w)
-                if nxt == (t, c):
-                    queued.add(nxt)
-                if nxt is not None:
-                    queue.append(nxt)
-    state["wg"] = None
+        for t, pos in direct.items():
+            assert ent[t][0] is None
+            ent[t][0] = pos
+            nxt = candidate(t, 0, BUDGET, None)
+            if nxt is not None:
+                queue.append(nxt)
     # the tail rounds
     worked = 0
     for r in range(rounds):
@@ -234,7 +226,7 @@ def split(s, with_out=False, late=False, rounds=ROUNDS_BLIND):
                 nxt_queue.append(node)
         queue = nxt_queue
     # successor pointers and the marking
-    ids = {(t, c): i for i, (t, c) in enumerate((t, c) for t in range(nseg) for c in range(len(ent[t])))}
+    ids = {(t, c): i for i, (t, c) in enumerate((t, c) for t in range(nseg) for c in range(len(ent[t])) if ent[t][c] is not None)}
     keys = list(ids)
     jump = []
     for t, c in keys:
