@@ -192,7 +192,9 @@ __device__ __forceinline__ void split_stage(const SplitParams& p, uint8_t* stage
 __device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos, bool* is_new, uint32_t* n_added) {
   uint32_t* e = p.ent + (pos / kSplitSeg) * kSplitCand;
   *is_new = false;
-  if (__hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (pos | kSplitTrusted)) return 0;
+  // (the look at slot 0 and the first compare-and-swap travel together: a walk along a chain is a chain of trips to
+  // memory, and this is one of them.  If slot 0 turns out to hold the position, the swap has listed it twice -- see above)
+  const uint32_t e0 = __hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t c = 1; c < kSplitCand; c++) {
     const uint32_t old = atomicCAS(&e[c], 0xffffffffu, pos | kSplitTrusted);
     if (old == 0xffffffffu) {
@@ -201,6 +203,7 @@ __device__ __forceinline__ uint32_t split_add(const SplitParams& p, uint32_t pos
       return c;
     }
     if (old == (pos | kSplitTrusted)) return c;
+    if (e0 == (pos | kSplitTrusted)) return 0;  // (slots 1 .. are somebody else's: the own slot holds it)
   }
   p.counters[1] = 1;
   return kSplitCand;
@@ -482,12 +485,16 @@ __global__ __launch_bounds__(kSplitWg) void split_tail_kernel(SplitParams p) {
       uint32_t next = kSplitNoNode;
       if (node != kSplitNoNode) {
         const uint32_t t = node / kSplitCand, c = node % kSplitCand;
+        // (the node's list entry, its segment's bytes and the first walk's summary in ONE trip: a hop is a few trips to
+        // memory and a walk; whether the node has been walked meanwhile -- by a follow-through, by the bulk launch, as a
+        // duplicate of the queue -- is looked at behind it)
         const uint32_t e = __hip_atomic_load(&p.ent[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (walked meanwhile: by a follow-through, by its wave's local rounds, as a duplicate of the queue)
-        if (__hip_atomic_load(&p.ext[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSplitPending && e != 0xffffffffu) {
-          split_stage_row(p, row, t);
-          next = split_candidate(p, row, t, c, e, p.cp[t], p.f_entry[t], p.f_code[t], p.f_ob[t], 0xffffffffu, 0xffffffffu, &n_added);
-        }
+        const uint32_t x = __hip_atomic_load(&p.ext[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t cp = p.cp[t];
+        const uint32_t fe = p.f_entry[t], fc = p.f_code[t], fo = p.f_ob[t];
+        split_stage_row(p, row, t);
+        if (x == kSplitPending && e != 0xffffffffu)
+          next = split_candidate(p, row, t, c, e, cp, fe, fc, fo, 0xffffffffu, 0xffffffffu, &n_added);
       }
       node = next;
     }

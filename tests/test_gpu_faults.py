@@ -133,3 +133,54 @@ def test_checksumming_ring_instantiation_variant():
                         os.path.join(ROOT, "tests", "test_gpu_batch.py") + "::test_units_the_index_pass_writes_itself"],
                        capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+SPLIT_PROBE = r'''
+import importlib, json, os, random, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tools"), os.path.join(%(root)r, "oracle"), os.path.join(%(root)r, "tests")]
+hip = importlib.import_module("nim-snappy_amd")
+import corpus, pyoracle as orc
+from conftest import golden_file
+assert hip.LIB_PATH == os.environ["SNAPPY_HIP_LIBRARY"]
+rng = random.Random(3)
+text = golden_file("alice29.txt") + golden_file("html")
+srcs = [corpus.make_blocks(0, 96).tobytes(), text[:300000], rng.randbytes(300000),
+        b"".join(rng.randbytes(rng.randint(1000, 9000)) * rng.randint(2, 4) for _ in range(40)),
+        (text[5000:5010] * 40000)[:400000]]
+ok = True
+comps = [orc.encode(src) for src in srcs]
+for src, comp in zip(srcs, comps):
+    ok = ok and hip.decode(comp) == src
+print("CLEAN STREAMS DONE", file=sys.stderr, flush=True)
+for comp in comps:  # damaged: the verdict (or the bytes) of the oracle
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x40
+    ok = ok and hip.decode(bytes(bad)) == orc.decode(bytes(bad))
+print(json.dumps({"ok": bool(ok)}))
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs,path", [("24,16", "none"), ("24,1", "looks"), ("24,0", "serial"), ("2,16", "none")])
+def test_raw_buffer_splitter_with_its_fallbacks_forced(knobs, path):
+    """uncompress of one raw multi-block buffer (split_kernels.h) enqueues its rounds without a look from the host; a
+    chain that is not complete behind them is walked again with a look a round, and what that cannot finish goes to the
+    one-workgroup walk.  A debug build of the same sources (-DSNAPPY_HIP_DEBUG: it reads SNAPPY_HIP_SPLIT_KNOBS =
+    "budget,hops") forces each: a tail round that follows a chain for one hop only leaves the corpus mix incomplete
+    behind the blind rounds ("looks"); one that walks nothing never completes anything ("serial"); a budget of two
+    elements sends nearly every second walk to the queue.  The bytes and the verdicts are the oracle's every time."""
+    lib = os.path.join(ROOT, "tools", "probes", "lib_dbg.so")
+    src = os.path.join(ROOT, "nim-snappy_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+        subprocess.run([os.path.join(ROOT, "tools", "mkvariant.sh"), "dbg", "-DSNAPPY_HIP_DEBUG"], check=True,
+                       capture_output=True, timeout=900)
+    env = dict(os.environ, SNAPPY_HIP_LIBRARY=lib, SNAPPY_HIP_SPLIT_KNOBS=knobs, SNAPPY_HIP_STATS="1")
+    p = subprocess.run([sys.executable, "-c", SPLIT_PROBE % {"root": ROOT}], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["ok"], p.stderr[-2000:]
+    clean = p.stderr.split("CLEAN STREAMS DONE")[0]  # (a damaged stream may take any of the paths)
+    again = "again, with looks" in clean
+    gave_up = any(ln.startswith("SPLIT look: root ->") and "root -> fffffffe" not in ln for ln in clean.splitlines())
+    assert again == (path != "none"), p.stderr[-1500:]
+    assert gave_up == (path == "serial"), p.stderr[-1500:]

@@ -10,6 +10,7 @@ VARIANTS = {
     "fault1": ["-DENC_INJECT_ORDER_FAULT=1", "-DD2_INJECT_GIVE_UP=1"],
     "fault7": ["-DENC_INJECT_ORDER_FAULT=7", "-DD2_INJECT_GIVE_UP=7"],
     "fusedcrc": ["-DD2_FUSED_CRC=1"],
+    "dbg": ["-DSNAPPY_HIP_DEBUG"],  # reads the debug knobs (SNAPPY_HIP_STATS, SNAPPY_HIP_SPLIT_KNOBS ...)
 }
 
 
