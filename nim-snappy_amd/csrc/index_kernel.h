@@ -167,15 +167,23 @@ __device__ __forceinline__ bool decode_element_bf(uint32_t tag, uint32_t b14, ui
 // then be decoded in parallel like independent units.  That works when no element straddles a
 // 64 KiB output boundary (true for every encoder that works in 64 KiB blocks, snappy.nim:49-62);
 // otherwise the unit is handed to the whole-stream kernel (kNeedsStreamKernel).
+// TEAM = true (round 5): the index pass of a SMALL batch -- kSplitWaves waves share a unit's walk the way SPLIT's do (a
+// unit's 32 chunks one after the other by one wave are ~250 us whatever the batch; 1 024 units leave three quarters of
+// the GPU's wave slots empty): 245 -> ~95 us for 1 024 units.  Of the units this pass writes itself (4.2) the one-literal
+// and one-period ones are written by the wave that concludes the walk; units of few long elements are left to the indexed
+// decoder's eight waves here (one wave's sparse decode of a unit is ~200 us: the longest thing in a small batch).
 // In SPLIT mode kSplitWaves waves share the walk: the tables of a chunk do not depend on where the
 // element chain enters it, so wave w prepares chunks w, w+4, ... ahead of time and only the short
 // chain step waits for the previous chunk's result (handed on through an LDS mailbox).
 constexpr uint32_t kSplitWaves = 4;
-template <bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_kernel(IndexParams prm) {
-  constexpr uint32_t W = SPLIT ? kSplitWaves : 1;
+template <bool SPLIT, bool TEAM = SPLIT>
+__global__ __launch_bounds__(TEAM ? 64 * kSplitWaves : 64) void index_units_kernel(IndexParams prm) {
+  static_assert(TEAM || !SPLIT, "SPLIT is a team's walk");
+  constexpr uint32_t W = TEAM ? kSplitWaves : 1;
   __shared__ uint32_t s_tab[W * 64 * kRowStride];
-  __shared__ uint32_t s_mail[8][4];  // SPLIT: [chunk & 7] = {chunk + 1, entry_abs, op, state | straddle << 2}
+  // TEAM: [chunk & 7] = {chunk + 1, entry_abs, op, state | straddle << 2, -, the first region's output bytes and elements}
+  __shared__ uint32_t s_mail[8][8];
+  __shared__ uint32_t s_left;  // TEAM, not SPLIT: waves that have run out of chunks (their index entries are written)
   // per tag byte: element length [0:7), stream size [7:14), bit 14 = literal with length bytes
   __shared__ uint16_t s_lut[256];
 
@@ -187,9 +195,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     const bool longlit = ty == 0 && hi6 >= 60;
     s_lut[tg] = (uint16_t)(longlit ? (1u << 14) : (len | (sz << 7)));
   }
-  const uint32_t wave = SPLIT ? readfirst(threadIdx.x >> 6) : 0;
-  if (SPLIT) {
-    if (threadIdx.x < 32) (&s_mail[0][0])[threadIdx.x] = 0;
+  const uint32_t wave = TEAM ? readfirst(threadIdx.x >> 6) : 0;
+  if (TEAM) {
+    if (threadIdx.x < 64) (&s_mail[0][0])[threadIdx.x] = 0;
+    if (threadIdx.x == 64) s_left = 0;
     __syncthreads();
   } else {
     wave_fence();
@@ -251,34 +260,40 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
   const uint32_t row = (wave * 64 + lane) * kRowStride;
   const uint32_t row8 = SPLIT ? (wave * 64 + lane) * kSizeStride : 0;
 
-  // SPLIT: hand the chain over to the wave that owns the next chunk / tell everybody to stop
+  // TEAM: hand the chain over to the wave that owns the next chunk / tell everybody to stop
+  uint32_t first_out = 0, first_n = 0;  // (uniform) the first region's chain: output bytes, elements
   auto post = [&](uint32_t ci, uint32_t state, uint32_t e_abs, uint32_t o, bool strad) {
     if (lane == 0) {
       uint32_t* m = s_mail[ci & 7];
       m[1] = e_abs;
       m[2] = o;
       m[3] = state | (strad ? 4u : 0u);
+      m[5] = first_out;
+      m[6] = first_n;
       asm volatile("" ::: "memory");
       __hip_atomic_store(&m[0], ci + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   };
   bool strad_before = false;  // SPLIT: a straddling element in an earlier chunk
+  bool concluded = false;     // TEAM, not SPLIT: this wave holds the walk's final state
   uint32_t n_elem_lane = 0;   // elements that start in my regions, over all chunks (sparse verdict)
-  uint32_t first_out = 0, first_n = 0;  // (uniform) the first region's chain: output bytes, elements
   unsigned long long tA = 0, tW = 0, tC = 0, tt0 = 0, tt1 = 0, tt2 = 0;  // DEBUG (SPLIT, prm.idx != nullptr)
   const bool dbgt = SPLIT && prm.idx != nullptr;
-  if (SPLIT && wave == 0) post(0, 0, 0, 0, false);
+  if (TEAM && wave == 0) post(0, 0, 0, 0, false);
 #ifndef IDX_NO_EARLY_PERIOD
-  if (!SPLIT && prm.sparse && n <= 4096) {
+  if (!SPLIT && prm.sparse && n <= 4096 && wave == 0) {
     // a unit that is one literal + copies of one offset is recognised from its stream and written at once: no walk
     // (sparse_kernel.h, early_period_unit with the total unknown); anything else: the walk below
+    // (TEAM: wave 0, in its own tables' LDS; the others build their chunks' tables meanwhile and are told to stop)
     uint32_t tot = 0;
     if (early_period_unit(in0, n, prm.out + prm.out_off[u], kPeriodTotalUnknown, s_tab, limit, exact, &tot)) {
       if (prm.sparse_counters && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(prm.sparse_counters), (unsigned long long)prm.in_len[u] + tot);
         atomicAdd(prm.sparse_counters + 2, 1u);
       }
-      return finish(kDoneEarly, tot);
+      finish(kDoneEarly, tot);
+      if (TEAM) post(1, 2, 0, 0, false);
+      return;
     }
     wave_fence();
   }
@@ -292,13 +307,13 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     // a verdict inside the loop: write it and, in SPLIT mode, stop the other waves
     auto bail = [&](uint32_t st) {
       finish(st, 0);
-      if (SPLIT) post(ci + 1, 2, 0, 0, false);
+      if (TEAM) post(ci + 1, 2, 0, 0, false);
     };
 
     if (dbgt) tt0 = __builtin_amdgcn_s_memtime();
     // (the tables of a chunk that a long literal covers entirely are not needed; SPLIT cannot
     // know that yet and builds them anyway)
-    if (SPLIT || entry_abs < c0 + kChunk) {
+    if (TEAM || entry_abs < c0 + kChunk) {
       // ---- my 32 region bytes + 8 bytes lookahead, from 16-byte aligned loads ---------------
       uint32_t w[10];
       {
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
         if (!ballot(changed)) break;
       }
     };
-    if (SPLIT) {
+    if (TEAM) {
       if (dbgt) tt1 = __builtin_amdgcn_s_memtime();
       // wait for the previous chunk's result
       uint32_t* m = s_mail[ci & 7];
@@ -494,6 +509,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
       entry_abs = readfirst(m[1]);
       op = readfirst(m[2]);
       const uint32_t fl = readfirst(m[3]);
+      first_out = readfirst(m[5]);
+      first_n = readfirst(m[6]);
       strad_before = (fl & 4) != 0;
       if (dbgt) tt2 = __builtin_amdgcn_s_memtime();
       if ((fl & 3) == 2) {  // somebody has written the verdict
@@ -593,13 +610,17 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
       first_n = readlane(nelem_here, 0);
     }
     op += tot;
-    if (SPLIT) {
-      const bool strad = strad_before || ballot(straddle) != 0;
+    if (TEAM) {
+      const bool strad = SPLIT && (strad_before || ballot(straddle) != 0);
       if (ended || c0 + kChunk >= n) {  // the walk is complete: I hold the final state
         uint32_t st = kOk;
         if (!ended && entry_abs != n) st = kInvalidInput;
         else if (exact && op != limit) st = kInvalidInput;  // snappy.nim:107-108
         else if (strad) st = kNeedsStreamKernel;
+        if (!SPLIT && st == kOk) {  // (the block decoder's index: the units this pass writes itself, below)
+          concluded = true;
+          break;
+        }
         finish(st, st == kOk ? op : 0);
         post(ci + 1, 2, 0, 0, false);
         return;
@@ -619,7 +640,17 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     dbg[1] = tW;
     dbg[2] = tC;
   }
-  if (SPLIT) return;  // (my chunks ran out; the wave that owns the last chunk concludes)
+  if (TEAM && !concluded) {  // (my chunks ran out; the wave that owns the last chunk concludes)
+    if (!SPLIT) {  // ... and may read the index entries I wrote (sparse_decode_unit): they have arrived when it sees the count
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&s_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+  if (TEAM) {  // the others have left: every chunk in front of my last one was theirs or mine (a wave without a chunk leaves at once)
+    while (__hip_atomic_load(&s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != W - 1) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
 
   // the chain must consume the stream exactly (every element was bounds-checked against n)
   if (!ended && entry_abs != n) return finish(kInvalidInput, 0);
@@ -628,8 +659,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     // Three kinds of unit this wave finishes itself, in the LDS of its tables (sparse_kernel.h): one literal; a literal
     // and copies of one offset (a period); few, long elements.  Their status, kDoneEarly, is carried past the indexed
     // decoder's launches.
-    static_assert(SPLIT || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
-    static_assert(SPLIT || sizeof(s_tab) >= 4096 + 4096 + 32, "... and the period's stream and image");
+    static_assert(TEAM || sizeof(s_tab) >= kSparseLds, "the sparse decoder works in the table's LDS");
+    static_assert(TEAM || sizeof(s_tab) >= 4096 + 4096 + 32, "... and the period's stream and image");
     uint8_t* const gptr = prm.out + prm.out_off[u];
     auto count_early = [&]() {  // (bench.py: the bytes of these units are this pass's, not the indexed decoder's)
       if (prm.sparse_counters && lane == 0) {
@@ -663,7 +694,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * kSplitWaves : 64) void index_units_ker
     } else {
       uint32_t n_elem;
       (void)wave_excl_scan(n_elem_lane, lane, &n_elem);
-      if (n_elem >= 2 && n_elem <= kSparseMax) {
+      if (!TEAM && n_elem >= 2 && n_elem <= kSparseMax) {
         // (the index entries were written by other lanes of this wave: the stores are waited for -- one wave, one CU)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();

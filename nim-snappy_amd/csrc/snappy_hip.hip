@@ -558,6 +558,7 @@ extern "C" int snappy_hip_pack_d(snappy_hip_ctx* c, const uint8_t* d_slots, uint
 }
 
 namespace {
+constexpr uint64_t kIndexTeamMaxUnits = 1024;  // (four workgroups of four waves a CU: 1 024 units are resident at once)
 int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
              const uint32_t* d_in_len, uint64_t n_units, int unit, const uint8_t* d_kind,
              uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
@@ -687,7 +688,12 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
     beside_index = nullptr;
     {
       LaunchTimer lt(c, s, 4);
-      LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
+      // a small batch: four waves a unit (index_kernel.h, TEAM) -- its units leave most of the GPU's wave slots empty
+      // anyway, and a unit's walk by one wave is ~250 us whatever the batch
+      if (n_units <= kIndexTeamMaxUnits && !dbg_env("SNAPPY_HIP_NO_INDEX_TEAM"))
+        LAUNCH((index_units_kernel<false, true>), dim3((uint32_t)n_units), dim3(64 * kSplitWaves), 0, s, ip);
+      else
+        LAUNCH(index_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, ip);
     }
     if (dbg_env("SNAPPY_HIP_VERIFY_INDEX")) {  // DEBUG
       uint32_t* d_rep;

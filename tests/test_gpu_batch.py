@@ -946,8 +946,11 @@ def test_sparse_units_decoder(hip, orc, torch_mod):
     n_el = []
     for b, p in units:
         assert orc.decode_all_tags(b, len(p)) == (0, p)
-    all_units = [(b, p, True) for b, p in units] + [(b, b"", False) for b in bad_units]
+    # (eleven times over: a batch of more than 1 024 units -- a smaller one goes through the index pass's team of four
+    # waves a unit, index_kernel.h TEAM, which leaves units of few long elements to the indexed decoder)
+    all_units = [(b, p, True) for b, p in units] * 11 + [(b, b"", False) for b in bad_units]
     nu = len(all_units)
+    assert nu > 1024
     in_off, out_off, pos, opos = [], [], 0, 0
     for k, (b, p, ok) in enumerate(all_units):
         in_off.append(pos)
@@ -975,20 +978,32 @@ def test_sparse_units_decoder(hip, orc, torch_mod):
         ctx.decode_blocks(d_stream, d_in_off, d_in_len, nu, d_dec, d_out_off, d_out_cap, d_out_len, d_status,
                           unit=hip.UNIT_BODY, d_crc=d_crc)
         ctx.sync()
-        assert ctx.kernel_ms(10)[1] - before >= 32  # (most of the 'rs' and 'manylits' units)
+        assert ctx.kernel_ms(10)[1] - before >= 32 * 11  # (most of the 'rs' and 'manylits' units)
         st = d_status.cpu().numpy()
         ol = d_out_len.cpu().numpy()
         got = d_dec.cpu().numpy()
+        crcs = d_crc.cpu().numpy() if with_crc else None
         for j, (b, p, ok) in enumerate(all_units):
-            want_st, want_out = orc.decode_all_tags(b, 65536)
+            want_st, want_out = orc.decode_all_tags(b, 65536) if (j < 96 or not ok) else (0, p)
             assert int(st[j]) == want_st, (j, int(st[j]), want_st)
             if ok:
                 assert want_st == 0 and int(ol[j]) == len(p)
                 assert got[out_off[j]:out_off[j] + len(p)].tobytes() == p, (with_crc, j)
-                if with_crc:
-                    assert int(d_crc[j].item()) & 0xffffffff == orc.masked_crc(p), j
+                if with_crc and j % 7 == 0:
+                    assert int(crcs[j]) & 0xffffffff == orc.masked_crc(p), j
             else:
                 assert want_st == hip.INVALID_INPUT and int(ol[j]) == 0
+    # the first 96 units alone: a small batch (the team of four waves a unit; these units through the indexed decoder)
+    d_out_len = torch.zeros(96, dtype=torch.int32, device="cuda")
+    d_status = torch.full((96,), 77, dtype=torch.int32, device="cuda")
+    d_dec = torch.zeros(opos, dtype=torch.uint8, device="cuda")
+    ctx.decode_blocks(d_stream, d_in_off, d_in_len, 96, d_dec, d_out_off, d_out_cap, d_out_len, d_status, unit=hip.UNIT_BODY)
+    ctx.sync()
+    got = d_dec.cpu().numpy()
+    assert not d_status.cpu().numpy().any()
+    for j in range(96):
+        p_j = all_units[j][1]
+        assert int(d_out_len[j].item()) == len(p_j) and got[out_off[j]:out_off[j] + len(p_j)].tobytes() == p_j, j
     ctx.close()
 
 
