@@ -1954,8 +1954,8 @@ int split_blocks_spec(snappy_hip_ctx* c, const uint8_t* d_tags, uint32_t n_tags,
     LAUNCH(split_tail_kernel, dim3(tgrid), dim3(kSplitWg), kSplitStage, s, sp);
   }
   // is the real chain complete?  mark what the root reaches; its last pointer tells
-  int steps = 1;  // four-fold pointer jumps that cover a chain of nseg nodes
-  while ((1ull << (2 * steps)) < (uint64_t)nseg + 1) steps++;
+  int steps = 1;  // kSplitJump-fold pointer jumps that cover a chain of nseg nodes
+  for (uint64_t reach_n = kSplitJump; reach_n < (uint64_t)nseg + 1; reach_n *= kSplitJump) steps++;
   LAUNCH(split_succ_kernel, dim3(ngrid), dim3(256), 0, s, sp, jump[0], reach, blk_any);
   int cur = 0;
   for (int k = 0; k < steps; k++, cur ^= 1)

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void split_init_kernel(uint32_t* ent_ext, uint
 constexpr uint32_t kSplitWg = 64;
 constexpr uint32_t kSplitRow = kSplitSeg + 4;
 constexpr uint32_t kSplitStage = kSplitWg * kSplitRow;  // 16 640 bytes: 13 pieces of LDS, nine waves a CU
-constexpr uint32_t kSplitBudget = 24;     // elements a second walk of the bulk launch may take (most meet the first walk within a dozen)
+constexpr uint32_t kSplitBudget = 64;     // elements a second walk of the bulk launch may take (most meet the first walk within a dozen)
 constexpr uint32_t kSplitMaxRounds = 13;  // tail launches at most (their queue lengths live in counters[2 .. 15])
 constexpr uint32_t kSplitNoNode = 0xffffffffu;
 extern __shared__ __attribute__((aligned(16))) uint8_t s_split_dyn[];
@@ -533,9 +533,10 @@ __global__ __launch_bounds__(256) void split_succ_kernel(SplitParams p, uint32_t
   if (threadIdx.x == 0) any[blockIdx.x] = (uint32_t)some;
 }
 
-// one step of the pointer jumping, four-fold (half the launches of doubling): a marked node marks the three
-// nodes its pointer leads to in one, two and three hops, every pointer then shows four times as far.  (Before
-// step k the marked nodes are those less than 4^k hops from the root; they mark 4^k, 2*4^k, 3*4^k further.)
+// one step of the pointer jumping, kSplitJump-fold (a third of the launches of doubling): a marked node marks the
+// nodes its pointer leads to in one, two ... kSplitJump - 1 hops, every pointer then shows kSplitJump times as far.
+// (Before step k the marked nodes are those less than J^k hops from the root; they mark J^k, 2 J^k ... further.)
+constexpr int kSplitJump = 8;
 // (A block without a node is never read: only a node is anybody's successor.)
 __global__ __launch_bounds__(256) void split_double_kernel(uint32_t n_nodes, const uint32_t* jump_in, uint32_t* jump_out,
                                                            uint8_t* reach, const uint32_t* any) {
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void split_double_kernel(uint32_t n_nodes, con
   uint32_t j = jump_in[node];
   const bool mark = j < kSplitFirstCode && reach[node];
 #pragma unroll
-  for (int hop = 0; hop < 3 && j < kSplitFirstCode; hop++) {
+  for (int hop = 0; hop < kSplitJump - 1 && j < kSplitFirstCode; hop++) {
     if (mark) reach[j] = 1;
     j = jump_in[j];
   }

@@ -39,7 +39,7 @@ def native(tag):
     return not ((tag & 3) == 3 or ((tag & 3) == 0 and (tag >> 2) >= 62))
 
 
-WG, BUDGET, HOPS, ROUNDS_BLIND, ROUNDS_MAX = 64, 24, 16, 4, 12
+WG, BUDGET, HOPS, ROUNDS_BLIND, ROUNDS_MAX, JUMP = 64, 64, 16, 4, 12, 8
 
 
 def split(s, with_out=False, rounds=ROUNDS_BLIND):
@@ -238,14 +238,14 @@ def split(s, with_out=False, rounds=ROUNDS_BLIND):
             jump.append(ids[(tt, ent[tt].index(x))] if x in ent[tt] else PENDING)
     reach = [False] * len(keys)
     reach[0] = True
-    steps = 1
-    while (1 << (2 * steps)) < nseg + 1:
-        steps += 1
-    for _ in range(steps):  # four-fold jumps: a marked node marks 1, 2 and 3 hops of the current pointers
+    steps, far = 1, JUMP
+    while far < nseg + 1:
+        steps, far = steps + 1, far * JUMP
+    for _ in range(steps):  # JUMP-fold jumps: a marked node marks 1 .. JUMP - 1 hops of the current pointers
         nj = list(jump)
         for i, j in enumerate(jump):
             mark = j >= 0 and reach[i]
-            for _hop in range(3):
+            for _hop in range(JUMP - 1):
                 if j < 0:
                     break
                 if mark:
