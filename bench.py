@@ -1153,6 +1153,10 @@ def main():
             del d_packed, d_out
             line["per_class"] = per_class_rates(hip, corpus, ctx, dev, min(nb, 16384))  # (16 waves of workgroups of the ring kernel)
             line["host_api"] = host_api_rates(hip, d_in[:min(nb, 16384) * BLOCK].cpu().numpy(), ctx, dev)
+            # (one raw multi-block buffer resident in HBM, snappy.nim:84-110 on the device: also at the line's top level)
+            for k in ("raw_buffer_uncompress_d_GBps", "raw_buffer_64MiB_uncompress_d_GBps"):
+                if k in line["host_api"]:
+                    line[k] = line["host_api"][k]
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
