@@ -16,6 +16,13 @@ d_out = torch.empty(len(src), dtype=torch.uint8, device="cuda")
 st, w = ctx.uncompress(d_in, len(raw), d_out, len(src))
 got = d_out.cpu().numpy().tobytes()
 print("status", st, "written", w, "of", len(src), "equal", got == src)
+import time
+ts = []
+for _ in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.uncompress(d_in, len(raw), d_out, len(src))
+    ts.append(time.perf_counter() - t0)
+print("%s x %d: %.3f ms = %.1f GB/s of output (stream %d bytes)" % (sys.argv[1], nb, min(ts) * 1e3, len(src) / min(ts) / 1e9, len(raw)))
 if got != src:
     bad = [i // 65536 for i in range(0, len(src), 65536) if got[i:i + 65536] != src[i:i + 65536]]
     print("blocks that differ:", bad[:20], len(bad), "of", (len(src) + 65535) // 65536)
