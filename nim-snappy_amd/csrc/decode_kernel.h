@@ -41,6 +41,7 @@ struct DecodeParams {
   int unit;
   int dbg;  // timing experiments only: 1 skip literals, 2 skip copies, 4 skip flush
   uint32_t only_status;  // block kernel: if non-zero, handle only units in this state
+  const uint32_t* list;  // optional: the units to take (list[-2] = how many); nullptr: unit = workgroup
 };
 
 constexpr int kUnitStored = 3;  // internal: verbatim bytes (uncompressed framed chunk)
@@ -65,12 +66,8 @@ __device__ __forceinline__ uint32_t parse_varint32(const uint8_t* p, uint32_t n,
 // OUT_GLOBAL = true : whole-stream kernel for anything larger; output and back-references go
 //                     through global memory (one wave, serial over the stream: SURVEY.md 8e).
 template <bool OUT_GLOBAL>
-__global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing + 16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_GLOBAL ? 16 : kMaxBlockLen + 16];
-
+__device__ __forceinline__ void decode_units_body(const DecodeParams& prm, uint64_t unit_idx, uint8_t* s_ring, uint8_t* s_out) {
   const uint32_t lane = lane_id();
-  const uint64_t unit_idx = blockIdx.x;
   if (unit_idx >= prm.n_units) return;
   const int unit = prm.kind ? (int)prm.kind[unit_idx] : prm.unit;
 
@@ -417,6 +414,42 @@ __global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
     }
   }
   finish(kOk, (uint32_t)op);
+}
+
+// prm.list == nullptr: workgroup i takes unit i.  Otherwise (the block decoder's fallback behind the indexed decoder,
+// round 5): the units are those of a list a small kernel has made (list[-2] = how many; decode_finish_kernel), taken by
+// however many workgroups were launched -- 65 536 workgroups of this kernel's 68 KB of LDS that look at a status and
+// leave cost 51 us a step; a list that is empty costs a load.
+template <bool OUT_GLOBAL>
+__global__ __launch_bounds__(64) void decode_units_kernel(DecodeParams prm) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_out[OUT_GLOBAL ? 16 : kMaxBlockLen + 16];
+  if (prm.list) {
+    const uint32_t n_list = __hip_atomic_load(prm.list - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
+      decode_units_body<OUT_GLOBAL>(prm, prm.list[i], s_ring, s_out);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (one wave: its LDS of this unit is done with)
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    decode_units_body<OUT_GLOBAL>(prm, blockIdx.x, s_ring, s_out);
+  }
+}
+
+// Behind the indexed decoder's launches: a unit the index pass decoded itself carried kDoneEarly past them and becomes
+// kOk here; the units the indexed decoder declined (kNeedsOnePass) are listed for decode_units_kernel<false>.
+__global__ __launch_bounds__(256) void decode_finish_kernel(uint32_t* status, uint64_t n_units, uint32_t* list) {
+  const uint64_t u = blockIdx.x * 256ull + threadIdx.x;
+  const uint32_t st = u < n_units ? status[u] : kOk;
+  if (st == kDoneEarly) status[u] = kOk;
+  const bool mine = st == kNeedsOnePass;
+  const uint64_t m = __ballot(mine);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(list - 2, (uint32_t)__builtin_popcountll(m));
+  base = __shfl(base, 0, 64);
+  if (mine) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)u;
 }
 
 }  // namespace snappy_hip

@@ -758,11 +758,18 @@ int decode_d(snappy_hip_ctx* c, const uint8_t* d_in, const uint64_t* d_in_off,
       (void)hipFree(d_stats);
     }
   }
-  if (!v1 && !dbg_env("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined
+  if (!v1 && !dbg_env("SNAPPY_HIP_NO_ONEPASS")) {  // units the indexed decoder declined: listed, then decoded
+    void* d_list;
+    int st = ws_get(c, 23, 8 + n_units * 4, &d_list);
+    if (st) return st;
+    HIP_TRY(hipMemsetAsync(d_list, 0, 8, s));
     LaunchTimer lt(c, s, 5);
+    LAUNCH(decode_finish_kernel, dim3((uint32_t)((n_units + 255) / 256)), dim3(256), 0, s, d_status, n_units, (uint32_t*)d_list + 2);
     p.only_status = kNeedsOnePass;
-    LAUNCH(decode_units_kernel<false>, dim3((uint32_t)n_units), dim3(64), 0, s, p);
+    p.list = (const uint32_t*)d_list + 2;
+    LAUNCH(decode_units_kernel<false>, dim3((uint32_t)(n_units < 512 ? n_units : 512)), dim3(64), 0, s, p);
     p.only_status = 0;
+    p.list = nullptr;
   }
   if (stream_pass) {
     LaunchTimer lt(c, s, 5);
