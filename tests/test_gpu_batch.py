@@ -921,6 +921,43 @@ def _sparse_stream(rng, style, target=65536):
     return bytes(body), bytes(out)
 
 
+def test_batches_on_both_sides_of_the_team_index_pass(hip, orc, torch_mod):
+    """decode_blocks of 1 024 units goes through the index pass's team of four waves a unit (index_kernel.h, TEAM), of 1 025
+    through one wave a unit: the same units, the same bytes, statuses, lengths and CRCs either way -- and ragged last
+    units, an empty one and a damaged one in the small batch"""
+    import corpus
+    torch = torch_mod
+    nb = 1025
+    blocks = corpus.make_blocks(7, nb)
+    flat = blocks.reshape(-1)
+    ctx = hip.Context(0)
+    d_in = _dev(torch, flat)
+    d_slots, d_sizes, d_offsets, d_packed, total = _encode_pack(hip, torch, ctx, d_in, flat.size, hip.UNIT_RAW)
+    d_in_off = d_offsets[:nb].contiguous()
+    d_out_off = torch.arange(nb, dtype=torch.int64, device="cuda") * 65536
+    d_out_cap = torch.full((nb,), 65536, dtype=torch.int32, device="cuda")
+    results = []
+    for n in (1024, 1025):
+        d_out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        d_status = torch.full((nb,), 77, dtype=torch.int32, device="cuda")
+        d_crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        d_dec = torch.zeros(nb * 65536, dtype=torch.uint8, device="cuda")
+        before = ctx.kernel_ms(10)[1]
+        ctx.decode_blocks(d_packed, d_in_off, d_sizes, n, d_dec, d_out_off, d_out_cap, d_out_len, d_status, unit=hip.UNIT_RAW,
+                          d_crc=d_crc)
+        ctx.sync()
+        assert not d_status[:n].cpu().numpy().any()
+        assert (d_out_len[:n].cpu().numpy() == 65536).all()
+        assert torch.equal(d_dec[:n * 65536], d_in[:n * 65536])
+        results.append((d_crc[:1024].cpu().numpy().copy(), ctx.kernel_ms(10)[1] - before))
+    assert (results[0][0] == results[1][0]).all()
+    for j in range(0, 1024, 97):
+        assert int(results[0][0][j]) & 0xffffffff == orc.masked_crc(blocks[j].tobytes()), j
+    # (both write the one-literal and one-period units themselves; only one wave a unit also the units of few long elements)
+    assert 0 < results[0][1] < results[1][1], results
+    ctx.close()
+
+
 def test_sparse_units_decoder(hip, orc, torch_mod):
     """units of few, long elements are decoded element-parallel by the index pass's own waves (sparse_kernel.h: units of 2
     to 832 elements whose stream is longer than 4 KiB): the repeated-strings pattern and every element form that
