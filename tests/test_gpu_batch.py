@@ -923,8 +923,8 @@ def _sparse_stream(rng, style, target=65536):
 
 def test_batches_on_both_sides_of_the_team_index_pass(hip, orc, torch_mod):
     """decode_blocks of 1 024 units goes through the index pass's team of four waves a unit (index_kernel.h, TEAM), of 1 025
-    through one wave a unit: the same units, the same bytes, statuses, lengths and CRCs either way -- and ragged last
-    units, an empty one and a damaged one in the small batch"""
+    through one wave a unit: the same units, the same bytes, statuses, lengths and CRCs either way (damaged and ragged
+    units in small batches: the mutation tests of this file, which all run through the team now)"""
     import corpus
     torch = torch_mod
     nb = 1025
