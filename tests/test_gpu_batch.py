@@ -121,12 +121,13 @@ def test_ragged_and_body_units(hip, orc, torch_mod):
     ctx.close()
 
 
-def test_corrupt_units_match_oracle(hip, orc, torch_mod):
-    """per-unit status of damaged streams == oracle's uncompress verdict"""
+@pytest.mark.parametrize("nb", [256, 1100])
+def test_corrupt_units_match_oracle(hip, orc, torch_mod, nb):
+    """per-unit status of damaged streams == oracle's uncompress verdict (256 units: the index pass's team of four waves a
+    unit; 1 100: one wave a unit -- index_kernel.h)"""
     import corpus
     torch = torch_mod
     rng = random.Random(99)
-    nb = 256
     blocks = corpus.make_blocks(5000, nb)
     units, caps = [], []
     for i in range(nb):
