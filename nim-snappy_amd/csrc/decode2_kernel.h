@@ -190,8 +190,14 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // step `s <- Z1024(s ^ dword)` per row): a row is final, and still in the ring, when its bytes are flushed, so
 // threads 256..511 take the rows the flush has just completed, their column registers live across the steps.
 // The framed stream (uncompressFramed, snappy.nim:231) then decodes on the ring kernel too.
+#ifndef D2_RING_MINWAVES  // (experiments: the register budget the compiler derives from "waves per SIMD")
+#define D2_RING_MINWAVES ((kD2Threads / 64 * d2_wgs_per_cu(WIN) + 3) / 4)
+#endif
+#ifndef D2_KATTR
+#define D2_KATTR
+#endif
 template <uint32_t WIN, bool RCRC = false>
-__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 * d2_wgs_per_cu(WIN) + 3) / 4 : 1) void decode_indexed_kernel(Decode2Params prm) {
+__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES : 1) D2_KATTR void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
   static_assert(RING || !RCRC, "the whole-block instantiation checksums its window at the end");
   constexpr uint32_t kOutSink = WIN;

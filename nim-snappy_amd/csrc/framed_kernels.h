@@ -362,8 +362,10 @@ __global__ __launch_bounds__(1024) void frame_stitch_kernel(const FrameChase* ch
   // Where the chain enters every slice, if all chasers ended on it: where the chaser before it stopped.  (The serial form
   // of this -- one thread, two loops over the 2 048 chasers, an LDS round trip each -- took 0.15 ms of a framed decode.  It
   // also let the chain pass OVER a slice; a data chunk is at most 76 KiB and a slice at least 1 MiB, so in a stream this
-  // walk applies to that only happens to the empty slices behind the stream's end: a non-empty slice the chain does not
-  // enter makes the stream irregular here, and the serial walk decides.)
+  // walk applies to that only happens to the empty slices behind the stream's end -- and to the LAST slice with bytes in it,
+  // which holds n mod slice bytes: when the final chunk starts in front of it the chain ends at n without entering it, and
+  // whatever its chaser took for headers inside that chunk's body is ignored.  Any other non-empty slice the chain does
+  // not enter makes the stream irregular here, and the serial walk decides.)
   for (uint32_t k = threadIdx.x; k < kFrameChasers; k += blockDim.x) {
     const uint64_t lo = k == 0 ? p0 : (uint64_t)k * slice;
     const uint64_t hi = (uint64_t)(k + 1) * slice < n ? (uint64_t)(k + 1) * slice : n;
@@ -371,10 +373,11 @@ __global__ __launch_bounds__(1024) void frame_stitch_kernel(const FrameChase* ch
     if (lo < n || k == 0) {  // (a slice with bytes in it)
       expect = k == 0 ? p0 : s_end[k - 1];
       if (expect >= hi) {
-        if (!(k == 0 && p0 >= n)) s_irregular = 1;  // (a stream of the header alone: nothing to walk)
+        // (a stream of the header alone: nothing to walk; the chain ended at the stream's end in front of the last slice)
+        if (!(k == 0 && p0 >= n) && !(expect == n && hi == n)) s_irregular = 1;
         expect = ~0ull;
       }
-      if (hi == n && s_end[k] != n && expect != ~0ull) s_irregular = 1;  // the last chaser must end at the stream's end
+      if (hi == n && s_end[k] != n && expect != ~0ull) s_irregular = 1;  // the last chaser the chain enters must end at the stream's end
     }
     s_expect[k] = expect;
   }

@@ -281,6 +281,9 @@ __global__ __launch_bounds__(TEAM ? 64 * kSplitWaves : 64) void index_units_kern
   const bool dbgt = SPLIT && prm.idx != nullptr;
   if (TEAM && wave == 0) post(0, 0, 0, 0, false);
 #ifndef IDX_NO_EARLY_PERIOD
+  // (wave 0 uses ITS OWN rows of s_tab as early_period_unit's scratch -- in a team the other waves are building their
+  // tables in the rows behind them meanwhile)
+  static_assert(64 * kRowStride * 4 >= kPeriodLdsBytes, "early_period_unit's scratch must fit one wave's table rows");
   if (!SPLIT && prm.sparse && n <= 4096 && wave == 0) {
     // a unit that is one literal + copies of one offset is recognised from its stream and written at once: no walk
     // (sparse_kernel.h, early_period_unit with the total unknown); anything else: the walk below

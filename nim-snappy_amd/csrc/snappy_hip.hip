@@ -118,6 +118,11 @@ struct snappy_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // work that runs beside the main stream's (a framed stream's stored chunks)
   hipEvent_t side_done = nullptr;
+  // One stream per context at a time (include/snappy_hip.h): the workspace, the encoder's work queue and the counters are
+  // the context's.  A call on another stream than the call before it first waits for that call's work (StreamTurn, below).
+  hipStream_t last_stream = nullptr;
+  hipEvent_t last_done = nullptr;
+  bool last_pending = false;
   uint32_t* d_crc_tab = nullptr;   // [4][256]
   uint32_t* d_col_mul = nullptr;   // [256]
   uint16_t* d_tag_lut = nullptr;   // [256] the decode front end's tag table (decode2_kernel.h)
@@ -185,6 +190,26 @@ struct LaunchTimer {
 hipStream_t pick_stream(snappy_hip_ctx* c, void* stream) {
   return stream ? (hipStream_t)stream : c->stream;
 }
+
+// A device-resident call's turn on its context: work that an earlier call left pending on ANOTHER stream is waited for on
+// this one before anything is enqueued (the two calls would otherwise share the workspace slots and the encoder's queue
+// counter -- skipped blocks, stale sizes), and the end of this call's work is marked for the next.  Same stream: nothing
+// to do, a stream is in order.
+struct StreamTurn {
+  snappy_hip_ctx* c;
+  hipStream_t s;
+  StreamTurn(snappy_hip_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+    if (c->last_pending && c->last_stream != s && c->last_done) (void)hipStreamWaitEvent(s, c->last_done, 0);
+  }
+  ~StreamTurn() {
+    if (c->last_done && hipEventRecord(c->last_done, s) == hipSuccess) {
+      c->last_stream = s;
+      c->last_pending = true;
+    }
+  }
+  StreamTurn(const StreamTurn&) = delete;
+  StreamTurn& operator=(const StreamTurn&) = delete;
+};
 
 // perm (in workspace slot `slot`, after `head` bytes the caller keeps there) = the n items in the
 // order of their keys' buckets (crc_pack_kernels.h): a counting sort in three small launches.
@@ -263,6 +288,7 @@ int ctx_init(snappy_hip_ctx* c) {
     HIP_TRY(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
   }
   HIP_TRY(hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming));
   // the indexed decoder's output window is dynamic LDS beyond the 64 KiB default limit
   HIP_TRY(hipFuncSetAttribute((const void*)decode_indexed_kernel<kMaxBlockLen>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)out_alloc(kMaxBlockLen) + 8192));
@@ -341,6 +367,7 @@ extern "C" void snappy_hip_ctx_destroy(snappy_hip_ctx* c) {
   (void)hipFree(c->d_seq_step);
   (void)hipFree(c->d_counters);
   if (c->side_done) (void)hipEventDestroy(c->side_done);
+  if (c->last_done) (void)hipEventDestroy(c->last_done);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -419,6 +446,7 @@ extern "C" int snappy_hip_crc32c_d(snappy_hip_ctx* c, const uint8_t* d_in, const
   p.stride_tab = c->d_crc_tab;
   p.col_mul = c->d_col_mul;
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   {
     LaunchTimer lt(c, s, 2);
     LAUNCH(crc32c_units_kernel, dim3((uint32_t)n_units), dim3(kCrcThreads), 0, s, p);
@@ -449,6 +477,17 @@ int crc_fixed_d(snappy_hip_ctx* c, const uint8_t* d_in, uint64_t total_len, uint
 }
 }  // namespace
 
+namespace {
+inline uint64_t host_batch_blocks() {  // SNAPPY_HIP_HOST_BATCH (read once): blocks per batch
+  static const uint64_t v = [] {
+    const char* e = getenv("SNAPPY_HIP_HOST_BATCH");
+    const long x = e ? atol(e) : 0;
+    return (uint64_t)(x >= 64 && x <= 65536 ? x : 2048);  // (measured: INTEGRATION.md)
+  }();
+  return v;
+}
+}  // namespace
+
 extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in,
                                           uint64_t total_len, uint32_t block_len, int unit,
                                           uint8_t* d_slots, uint32_t slot_stride,
@@ -462,6 +501,7 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   if (nb > 0x7fffffffull) return SNAPPY_HIP_INVALID_INPUT;
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   uint32_t* d_crc = nullptr;
   if (unit == kUnitFrame) {
     void* p;
@@ -504,7 +544,11 @@ extern "C" int snappy_hip_encode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
     // four workgroups; a batch that does not fill the GPU's LDS-table waves starts none.
     const uint32_t resident = 4u * (uint32_t)c->n_cus;
     const uint32_t grid = nb < resident ? (uint32_t)nb : resident;
-    uint32_t g_per4 = nb >= (c->enc_g_min_blocks ? c->enc_g_min_blocks : 2 * (uint64_t)resident) ? c->enc_g_per4 : 0;
+    // (from twice the resident workgroups on -- but never above a host-buffer call's batch, whatever the part's CU count:
+    // the two defaults are one expression)
+    const uint64_t g_min = c->enc_g_min_blocks ? c->enc_g_min_blocks
+                                               : (2 * (uint64_t)resident < host_batch_blocks() ? 2 * (uint64_t)resident : host_batch_blocks());
+    uint32_t g_per4 = nb >= g_min ? c->enc_g_per4 : 0;
     void* qp;
     int st = ws_get(c, 21, 64 + (g_per4 ? (size_t)grid * kMaxTableSize * 2 : 0), &qp);
     if (st) return st;
@@ -547,6 +591,7 @@ extern "C" int snappy_hip_pack_d(snappy_hip_ctx* c, const uint8_t* d_slots, uint
                                  uint8_t* d_out, uint64_t* d_offsets, void* stream) {
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   LaunchTimer lt(c, s, 3);
   LAUNCH(scan_sizes_kernel, dim3(1), dim3(kScanThreads), 0, s, d_sizes, n_blocks, base,
                      d_offsets);
@@ -802,6 +847,7 @@ extern "C" int snappy_hip_decode_blocks_d(snappy_hip_ctx* c, const uint8_t* d_in
   if (unit != kUnitBody && unit != kUnitRaw) return SNAPPY_HIP_INVALID_INPUT;
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   return decode_d(c, d_in, d_in_off, d_in_len, n_units, unit, nullptr, d_out, d_out_off, d_out_cap,
                   d_out_len, d_status, true, s, d_crc);
 }
@@ -817,6 +863,7 @@ extern "C" int snappy_hip_compress_framed_d(snappy_hip_ctx* c, const uint8_t* d_
   if (cap < snappy_hip_max_compressed_len_framed((int64_t)n)) return SNAPPY_HIP_BUFFER_TOO_SMALL;  // snappy.nim:139-140
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   HIP_TRY(hipMemcpyAsync(d_out, kFramingHeader, sizeof kFramingHeader, hipMemcpyHostToDevice, s));
   const uint64_t nb = (n + kMaxBlockLen - 1) / kMaxBlockLen;
   uint64_t end = sizeof kFramingHeader;
@@ -850,6 +897,7 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
   *written_out = 0;
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   FrameScanResult res{};
   FrameUnits comp{}, stored{};
   uint32_t *comp_status = nullptr, *comp_len = nullptr, *comp_crc = nullptr, *stored_crc = nullptr;
@@ -1662,15 +1710,6 @@ int run_batches(size_t n_batches, snappy_hip_ctx* own, F fn) {
 // encoded and packed on one context while its neighbours are on theirs (run_batches); a batch's
 // place in the output is the sum of the batches in front of it -- the reference's serial
 // `written += ...` (snappy.nim:59-62, :149-153) -- so its download waits for their sizes only.
-inline uint64_t host_batch_blocks() {  // SNAPPY_HIP_HOST_BATCH (read once): blocks per batch
-  static const uint64_t v = [] {
-    const char* e = getenv("SNAPPY_HIP_HOST_BATCH");
-    const long x = e ? atol(e) : 0;
-    return (uint64_t)(x >= 64 && x <= 65536 ? x : 2048);  // (measured: INTEGRATION.md)
-  }();
-  return v;
-}
-
 int encode_host(snappy_hip_ctx* own, const uint8_t* in, size_t n, int unit, uint8_t* out, size_t cap,
                 uint64_t base, uint64_t* total) {
   const uint64_t nb = (n + kMaxBlockLen - 1) / kMaxBlockLen;
@@ -2128,6 +2167,7 @@ extern "C" int snappy_hip_uncompress_d(snappy_hip_ctx* c, const uint8_t* d_in, u
   *written = 0;
   DeviceGuard guard(c->device);
   hipStream_t s = pick_stream(c, stream);
+  StreamTurn turn(c, s);
   if (n > 0xffffffffull) return SNAPPY_HIP_INVALID_INPUT;
   uint8_t hb[8] = {0};
   const size_t hn = n < 8 ? (size_t)n : 8;

@@ -388,6 +388,7 @@ __device__ __forceinline__ void early_literal_unit(const uint8_t* src, uint8_t* 
 // what the caller wants (exact: the declared length, snappy.nim:107-108; else at most `limit`).  Anything else returns
 // false and the walk decides.  A period unit then never walks its chain (~40 of the ~125 us it held a wave slot).
 constexpr uint32_t kPeriodTotalUnknown = 0xffffffffu;
+constexpr uint32_t kPeriodLdsBytes = 4096 + 4096 + 32;  // the stream, the image, what the image's last reader looks at behind it
 __device__ __forceinline__ bool early_period_unit(const uint8_t* in0, uint32_t n, uint8_t* gout, uint32_t total, uint32_t* lds,
                                                   uint32_t limit = 0, bool exact = false, uint32_t* total_out = nullptr) {
   const uint32_t lane = lane_id();

@@ -637,8 +637,8 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
   uint32_t pos = p.entry[s];
   const uint32_t seg_lo = s * kSplitSeg;
   const uint32_t seg_hi = seg_lo + kSplitSeg < p.n ? seg_lo + kSplitSeg : p.n;
-  if (pos >= seg_hi) {  // (cannot be: a segment that puts out bytes has an entry)
-    p.flags[1] = 1;
+  if (pos >= seg_hi) {  // (cannot be: a segment that puts out bytes has an entry -- an inconsistency of the split's own
+    p.flags[2] = 1;     // machinery is no verdict on the stream: the caller falls back to the one-workgroup walk)
     return;
   }
   split_stage_row(p, row, s);
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
     uint32_t L, size;
     bool nat;
     if (!split_element(row, pos - seg_lo, p.n - pos - 1, &L, &size, &nat)) {
-      p.flags[1] = 1;
+      p.flags[2] = 1;  // (cannot be either: the marked chain's walks decoded every one of these elements -- fall back)
       return;
     }
     op += L;
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(kSplitWg) void split_locate_kernel(SplitParams p) {
 
 // the blocks as units of the block decoder, from where they start in the stream (blk_in[k], k >= 1; block 0 at 0)
 // *bad: 1 = a block without a start (the caller falls back to the serial walk), 2 = the stream is invalid (its
-// elements do not produce the declared length, snappy.nim:107-108, or the last walk met an invalid one), 4 = an
-// element straddles a 64 KiB boundary (a foreign encoder: fall back) -- the speculative split's verdicts, looked
+// elements do not produce the declared length, snappy.nim:107-108), 4 = an element straddles a 64 KiB boundary (a
+// foreign encoder) or the last walk contradicts the marking (cannot be): fall back -- the speculative split's verdicts, looked
 // at by the host once, behind the decode
 __global__ __launch_bounds__(256) void split_table_kernel(const uint32_t* blk_in, uint32_t nblk, uint32_t n_tags,
                                                           uint32_t hdr, uint64_t len, uint64_t* in_off, uint32_t* in_len,
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void split_table_kernel(const uint32_t* blk_in
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k == 0 && total) {
     uint32_t v = 0;
-    if (*total != len || flags[1]) v |= 2;
+    if (*total != len) v |= 2;
     if (flags[2]) v |= 4;
     if (v) atomicOr(bad, v);
   }

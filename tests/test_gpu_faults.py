@@ -184,3 +184,61 @@ def test_raw_buffer_splitter_with_its_fallbacks_forced(knobs, path):
     gave_up = any(ln.startswith("SPLIT look: root ->") and "root -> fffffffe" not in ln for ln in clean.splitlines())
     assert again == (path != "none"), p.stderr[-1500:]
     assert gave_up == (path == "serial"), p.stderr[-1500:]
+
+
+FRAMED_TAIL_PROBE = r'''
+import importlib, json, os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "tools"), os.path.join(%(root)r, "oracle"), os.path.join(%(root)r, "tests")]
+import numpy as np, torch
+hip = importlib.import_module("nim-snappy_amd")
+import corpus, pyoracle as orc
+assert hip.LIB_PATH == os.environ["SNAPPY_HIP_LIBRARY"]
+MiB = 1 << 20
+rng = np.random.default_rng(11)
+body = corpus.make_blocks(0, 160).tobytes()
+rnd = [rng.integers(0, 256, 65536, dtype=np.uint8).tobytes() for _ in range(17)]  # stored chunks: 65 544 bytes each
+body_stream = orc.encode_framed(body)
+rnd_chunks = [orc.encode_framed(b)[10:] for b in rnd]
+assert all(len(c) == 65544 and c[0] == 1 for c in rnd_chunks)
+ctx = hip.Context(0)
+res = []
+for r in %(tails)r:  # bytes of the stream in its last slice of 1 MiB; the last chunk is a stored one of 65 544 bytes
+    # k more stored chunks and one small padding chunk (snappy.nim:262-263) behind the stream identifier give the length
+    k, pad = min(((k, (r - len(body_stream) - (k + 1) * 65544) %% MiB) for k in range(16)), key=lambda t: t[1] if t[1] >= 4 else MiB)
+    assert 4 <= pad < 70000
+    s = body_stream[:10] + b"\xfe" + (pad - 4).to_bytes(3, "little") + bytes(pad - 4) + body_stream[10:] + b"".join(rnd_chunks[:k + 1])
+    src = body + b"".join(rnd[:k + 1])
+    assert len(s) >= 4 * MiB and len(s) %% MiB == r
+    d_in = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(len(src), dtype=torch.uint8, device="cuda")
+    print("TAIL %%d" %% r, file=sys.stderr, flush=True)
+    st, rd, wr = ctx.uncompress_framed(d_in, len(s), d_out, len(src))
+    res.append({"tail": r, "st": st, "rd_ok": rd == len(s), "wr_ok": wr == len(src),
+                "bytes_ok": bytes(d_out.cpu().numpy().tobytes()) == src})
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.gpu
+def test_framed_stream_whose_last_chunk_covers_its_last_slice():
+    """The parallel chunk walk (framed_kernels.h) cuts the stream into slices of 1 MiB; when the final chunk starts in
+    front of the last slice and ends at the stream's end, the chain never enters that slice (n mod 1 MiB bytes, all of
+    them inside the chunk's body).  Round 5's stitch called such a stream irregular and sent it to the serial walk --
+    right bytes, five times the time, for 2-4 %% of all stream lengths.  A debug build says which walk ran."""
+    lib = os.path.join(ROOT, "tools", "probes", "lib_dbg.so")
+    src = os.path.join(ROOT, "nim-snappy_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+        subprocess.run([os.path.join(ROOT, "tools", "mkvariant.sh"), "dbg", "-DSNAPPY_HIP_DEBUG"], check=True,
+                       capture_output=True, timeout=900)
+    tails = [4, 1000, 65543, 65544, 65545, 300000]
+    env = dict(os.environ, SNAPPY_HIP_LIBRARY=lib, SNAPPY_HIP_STATS="1")
+    p = subprocess.run([sys.executable, "-c", FRAMED_TAIL_PROBE % {"root": ROOT, "tails": tails}], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r["tail"] for r in res] == tails
+    for r in res:
+        assert r["st"] == 0 and r["rd_ok"] and r["wr_ok"] and r["bytes_ok"], r
+    for part in p.stderr.split("TAIL ")[1:]:  # every one of them by the parallel walk
+        assert "FRAME WALK stitch irregular 0" in part and "fast_ok 1" in part, part[:600]
