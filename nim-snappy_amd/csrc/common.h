@@ -91,14 +91,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan_max(uint32_t v, uint32_t lane
   x = mx(x, dpp_mov0<0x112>(x));
   x = mx(x, dpp_mov0<0x114>(x));
   x = mx(x, dpp_mov0<0x118>(x));
-  {
-    const uint32_t t = dpp_mov0<0x142>(x);  // row_bcast:15
-    if ((lane & 31) >= 16) x = mx(x, t);
-  }
-  {
-    const uint32_t t = dpp_mov0<0x143>(x);  // row_bcast:31
-    if (lane >= 32) x = mx(x, t);
-  }
+  // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 only -- the DPP row mask; the other rows get 0, the
+  // identity: no per-lane condition, whose lane masks the compiler kept in spilled scalar registers)
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+  x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+  (void)lane;
   *total = readlane(x, 63);
   return dpp_mov0<0x138>(x);  // wave_shr:1: the inclusive maximum of the lane before me
 }

@@ -112,6 +112,13 @@ struct Decode2Params {
   const uint16_t* tag_lut;  // kTagLut in device memory: what a tag byte says about its element (see the front end)
 };
 
+// (keeps a rarely taken condition a BRANCH: the compiler cannot fold what follows an asm statement into scalar selects
+// that every pass through the code then executes)
+__device__ __forceinline__ bool asm_nop() {
+  asm volatile("");
+  return true;
+}
+
 // Branch-free element decode (decoder.nim:42-109); no validity checks, the index pass did them.
 __device__ __forceinline__ void decode_fast(uint32_t tag, uint32_t b14, bool* is_copy, uint32_t* L,
                                             uint32_t* size, uint32_t* hdr, uint32_t* off) {
@@ -955,7 +962,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
         // inside it, one group per trip, once it is my turn.  run_end = first byte after them.
         // (only groups of few, long elements are examined: tot = element starts in the group)
         uint32_t run_off = 0, run_end = 0;
-        if (__builtin_expect(tot <= kGroup / 32 + 1 && g >= cb && g + kGroup <= cn && (run_off = readfirst(offj[0])) != 0, 0)) {
+        if (__builtin_expect(tot <= kGroup / 32 + 1, 0) && (asm_nop(), g >= cb && g + kGroup <= cn) && (run_off = readfirst(offj[0])) != 0) {
 #pragma unroll
           for (uint32_t j = 0; j < B; j++) off_differs = off_differs || offj[j] != run_off;
           if (ballot(off_differs) == 0) {
@@ -1043,9 +1050,12 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
           }
           // A run is extended inside the ring: its sources must still be there.  (Otherwise group by group,
           // like any other.)
-          if (run_end > g + kGroup) {
-            const uint32_t lo = g >= run_off + 1024 ? g - run_off - 1024 : 0;  // (below every source it reads)
-            if (lo < ring_lo) run_end = 0;
+          if (__builtin_expect(run_end != 0, 0)) {  // (a branch, not a dozen scalar selects in every group: the empty asm pins it)
+            asm volatile("");
+            if (run_end > g + kGroup) {
+              const uint32_t lo = g >= run_off + 1024 ? g - run_off - 1024 : 0;  // (below every source it reads)
+              if (lo < ring_lo) run_end = 0;
+            }
           }
         }
         // how many of the groups after mine are skipped: I publish them with mine

@@ -384,6 +384,11 @@ def test_bench_contract_and_two_rank_path(hip):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_step", "traffic_step",
                 "traffic_over_algorithmic")) <= set(j["roofline"])
     assert 0 < j["roofline"]["frac_step"] < 1
+    # the side numbers live INSIDE `roofline` (the driver's record keeps that dict whole): value + fraction of the HBM peak
+    for k in ("decompress_step", "compress", "round_trip", "framed", "framed_compress"):
+        assert j["roofline"][k]["value"] > 0 and 0 < j["roofline"][k]["frac"] < 1, k
+    assert j["roofline"]["framed"]["stream_bytes"] > 10 and j["roofline"]["framed"]["calls"] == 2
+    assert abs(j["roofline"]["decompress_step"]["value"] - j["value"]) < 0.01 * j["value"]
     assert j["framed_decompress_calls"] == 2 and j["framed_decompress_best_GBps"] >= j["framed_decompress_GBps"] > 0
     assert j["library"] == {"path": os.path.join("nim-snappy_amd", "libsnappy_hip.so"), "overridden": False}
     # a variant library is refused unless asked for
