@@ -43,7 +43,9 @@ enum Unit : int { kUnitBody = 0, kUnitRaw = 1, kUnitFrame = 2 };
 
 // ---- wave64 helpers --------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// (the builtin on the predicate itself: HIP's __ballot(int) turns the predicate into 0 / 1 and compares that with 0 again --
+// two vector instructions per ballot, and the kernels' loops are full of ballots)
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
@@ -71,14 +73,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
   x += dpp_mov0<0x112>(x);  // row_shr:2
   x += dpp_mov0<0x114>(x);  // row_shr:4
   x += dpp_mov0<0x118>(x);  // row_shr:8
-  {
-    const uint32_t t = dpp_mov0<0x142>(x);  // row_bcast:15 -> lane 15 of a row into the next row
-    if ((lane & 31) >= 16) x += t;
-  }
-  {
-    const uint32_t t = dpp_mov0<0x143>(x);  // row_bcast:31 -> lane 31 into lanes 32..63
-    if (lane >= 32) x += t;
-  }
+  // row_bcast:15 -> lane 15 of a row into the next row (rows 1 and 3 only: the DPP row mask; the others add 0);
+  // row_bcast:31 -> lane 31 into lanes 32..63
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+  (void)lane;
   *total = readlane(x, 63);
   return x - v;
 }

@@ -230,7 +230,12 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
   __shared__ uint32_t s_err;
   // a long literal that covers whole steps: (first step after it) << 16 | (first step that may be skipped)
   __shared__ uint32_t s_skip;
-  __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup];  // list slot of the element covering byte 256 m
+  // list slot of the element covering byte 256 m (eight entries of slack: the resolvers look one round of groups ahead,
+  // past the unit's end at its last step -- what they read there is never used)
+  __shared__ uint16_t s_gidx[kMaxBlockLen / kGroup + 8];
+  // s + 1 where step s (list s & 1) holds a literal with length bytes that covers whole groups: only then do the
+  // resolvers of that step look for groups to skip (text has next to none: a look per group saved)
+  __shared__ uint32_t s_big[2];
   __shared__ uint32_t s_crc_acc, s_crc_cnt;            // the unit's CRC: XOR of the waves' parts, waves done
   __shared__ uint32_t s_runbad;                          // the unit is not one literal + copies of one offset
   __shared__ uint32_t s_rcrc_tab[RCRC ? 1024 : 1];       // (ring + CRC) the four stride tables of the column scheme
@@ -365,6 +370,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
     s_crc_acc = 0;
     s_crc_cnt = 0;
     s_runbad = 0;
+    s_big[0] = 0;
+    s_big[1] = 0;
   }
 
   // ring[q & 4095] = stream byte q - shift; at the start of step s it holds q in
@@ -829,6 +836,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
           if (to > s + 2 && lane == 0) atomicMax(&s_skip, (to << 16) | (s + 2));
         }
         // every 256-byte boundary the literal covers maps to its slot
+        if (lane == 0) s_big[buf] = s + 1;
         for (uint32_t m = (ed + kGroup - 1) / kGroup + lane; m * kGroup < ed + eL; m += 64)
           s_gidx[m & (kMaxBlockLen / kGroup - 1)] = (uint16_t)(eslot | 0x8000u);  // flag: inside a long literal
         // destination-aligned: up to 15 head bytes one per lane, then 16-byte pieces whose LDS store
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
       // boundaries such a literal covers); nobody works on it, the group before it publishes it
       auto is_skip = [&](uint32_t gg) -> bool {  // gg > cb (per lane)
         const uint32_t a = s_gidx[gg / kGroup];
-        const uint32_t b2 = s_gidx[(gg / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
+        const uint32_t b2 = s_gidx[gg / kGroup + 1];
         return (a & 0x8000u) && gg + kGroup < cn && a == b2;
       };
       uint32_t front = cb;  // what I know of s_front
@@ -885,8 +893,9 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
       // (a group's first words -- who covers its first byte, whether the group behind it is inside a long literal --
       // are requested while the group before it is worked on: one round trip less on the wave's path)
       uint32_t g = gfirst + (wave - kPoolFirst) * kGroup;
-      uint32_t ge_raw = s_gidx[(g / kGroup) & (kMaxBlockLen / kGroup - 1)];
-      uint32_t gn_raw = s_gidx[(g / kGroup + 1) & (kMaxBlockLen / kGroup - 1)];
+      const bool has_big = readfirst(s_big[buf]) == s;  // (this list's step is s - 1)
+      uint32_t ge_raw = s_gidx[g / kGroup];
+      uint32_t gn_raw = has_big ? s_gidx[g / kGroup + 1] : 0u;
       // (an empty step has nothing to resolve -- and after a fast-forward its list is not even its own)
       for (; g < cn && cb < cn; g += kPool * kGroup) {
         const unsigned long long tg0 = now();
@@ -894,8 +903,8 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
         const uint32_t gnext = readfirst(gn_raw);
         {
           const uint32_t gm = (g + kPool * kGroup) / kGroup;
-          ge_raw = s_gidx[gm & (kMaxBlockLen / kGroup - 1)];
-          gn_raw = s_gidx[(gm + 1) & (kMaxBlockLen / kGroup - 1)];
+          ge_raw = s_gidx[gm];
+          if (has_big) gn_raw = s_gidx[gm + 1];
         }
         if ((ge & 0x8000u) && readfirst(is_skip(g) ? 1u : 0u)) continue;  // (flag first: one read for most groups)
         acc_c++;
@@ -1095,30 +1104,35 @@ __global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES :
         // (from here to the publish this wave is, or is about to be, on the step's critical path)
         __builtin_amdgcn_s_setprio(3);
 #ifndef D2_LOOSE_POLL
-        // (the wait is written out: read, wait, compare -- five instructions a poll; the compiler's form of the
-        // loop below took eighteen scalar instructions a poll, and the scalar unit is shared by the CU's waves)
+        // (the wait is written out.  Round 3: read, wait, readfirstlane, compare, branch + a bounded counter -- eight
+        // instructions a look, six of them scalar, where the compiler's loop took eighteen.  Round 6: the comparison is a
+        // vector compare into VCC -- every lane reads the same word -- and the counter is stepped once per four looks:
+        // four instructions a look, two of them scalar.  A turn is looked for ~15 times, the scalar unit is shared by the
+        // CU's 32 waves, and the looks were a third of the scalar instructions of a group.)
 #ifdef D2_INJECT_GIVE_UP  // (tests/test_gpu_faults.py: every k-th turn that has to be waited for is given up on at once)
-        const uint32_t looks = (front < expect && (++d2_inject % (D2_INJECT_GIVE_UP)) == 0) ? 1 : 1024;
+        const uint32_t looks = (front < expect && (++d2_inject % (D2_INJECT_GIVE_UP)) == 0) ? 1 : 256;
 #else
-        constexpr uint32_t looks = 1024;
+        constexpr uint32_t looks = 256;
 #endif
-        for (uint32_t spin = looks == 1024 ? 0 : 400001; front < expect; spin += 1024) {
+        for (uint32_t spin = looks == 256 ? 0 : 400001; front < expect; spin += 1024) {
           uint32_t left = looks, fv;
           const uint32_t fa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&s_front;
+#define D2_LOOK                       \
+  "ds_read_b32 %[fv], %[fa]\n"        \
+  "s_waitcnt lgkmcnt(0)\n"            \
+  "v_cmp_le_u32_e32 vcc, %[ex], %[fv]\n" \
+  "s_cbranch_vccnz 2f\n"
           asm volatile(
-              "1:\n"
-              "ds_read_b32 %[fv], %[fa]\n"
-              "s_waitcnt lgkmcnt(0)\n"
-              "v_readfirstlane_b32 %[fr], %[fv]\n"
-              "s_cmp_ge_u32 %[fr], %[ex]\n"
-              "s_cbranch_scc1 2f\n"
+              "1:\n" D2_LOOK D2_LOOK D2_LOOK D2_LOOK
               "s_sub_u32 %[left], %[left], 1\n"
               "s_cmp_lg_u32 %[left], 0\n"
               "s_cbranch_scc1 1b\n"
               "2:\n"
+              "v_readfirstlane_b32 %[fr], %[fv]\n"
               : [fr] "+s"(front), [fv] "=&v"(fv), [left] "+s"(left)
               : [fa] "v"(fa), [ex] "s"(expect)
-              : "scc", "memory");
+              : "scc", "vcc", "memory");
+#undef D2_LOOK
           if (front >= expect) break;
           if (spin > 400000 || s_err != 0) {
             // cannot happen on a consistent index; never hang the GPU
