@@ -865,6 +865,38 @@ def test_pool_release_and_caller_stream(hip, orc, torch_mod):
     ctx.close()
 
 
+def test_one_context_on_two_streams_back_to_back(hip, orc, torch_mod):
+    """include/snappy_hip.h: one stream per context at a time.  A caller that hands a context to another stream without a
+    synchronisation in between used to get two launches sharing the context's workspace -- the encoder's work-queue counter
+    among it: skipped blocks, stale sizes.  Since round 6 a call on another stream than the call before it first waits for
+    that call's work (an event), so the results are the oracle's whatever the streams."""
+    import corpus
+    torch = torch_mod
+    nb = 2304  # (above the encoder's second-wave threshold: the queue and the tables in global memory are in use)
+    a = corpus.make_blocks(11, nb)
+    b = corpus.make_blocks(5011, nb)
+    ctx = hip.Context(0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d = []
+    for arr in (a, b):
+        d_in = _dev(torch, arr.reshape(-1))
+        d.append((d_in, torch.zeros(nb * hip.SLOT_STRIDE, dtype=torch.uint8, device="cuda"),
+                  torch.zeros(nb, dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    for rep in range(3):  # enqueued back to back, nothing waited for in between
+        ctx.encode_blocks(d[0][0], nb * 65536, d[0][1], d[0][2], stream=s1.cuda_stream)
+        ctx.encode_blocks(d[1][0], nb * 65536, d[1][1], d[1][2], stream=s2.cuda_stream)
+    s1.synchronize()
+    s2.synchronize()
+    for arr, (d_in, d_slots, d_sizes) in zip((a, b), d):
+        sizes = d_sizes.cpu().numpy()
+        slots = d_slots.cpu().numpy().reshape(nb, hip.SLOT_STRIDE)
+        for i in list(range(0, nb, 97)) + [nb - 1]:
+            assert slots[i, :sizes[i]].tobytes() == orc.encode(arr[i].tobytes()), i
+        assert int((sizes <= 0).sum()) == 0
+    ctx.close()
+
+
 def _sparse_stream(rng, style, target=65536):
     """One block's tag stream of FEW, LONG elements (sparse_kernel.h): long literals with stretches of copies behind
     them -- the repeated-strings pattern -- plus everything that kernel treats specially: literals of every length
