@@ -19,15 +19,19 @@
  * host-buffer calls take a context from a process-wide pool (one per concurrent call; created on
  * demand on the GPU SNAPPY_HIP_DEVICE names, default 0) and run side by side; large inputs go in
  * batches on up to three worker threads so that upload, kernels and download overlap.  An explicit
- * context (snappy_hip_ctx_create) serves one thread (and one stream) at a time: it owns scratch
- * buffers that its calls reuse.  Every entry point makes its context's device current for the
- * call and restores the caller's.
+ * context (snappy_hip_ctx_create) serves one thread at a time: it owns scratch buffers that its
+ * calls reuse.  Its calls may name different streams: a call on another stream than the call
+ * before it first waits -- on the device, through an event -- for that call's work, so the two
+ * never share the scratch (they run one after the other; for work side by side use a context
+ * each).  Every entry point makes its context's device current for the call and restores the
+ * caller's.
  *
  * Environment (read once, by the host-buffer calls only; the device-resident API reads one, at context creation):
  *   SNAPPY_HIP_ENC_GWAVES    "g" or "g,min_blocks" (every context): of four encoder workgroups, g (0..4, default 4) run a
  *                            second wave whose hash table lies in global memory (csrc/encode_kernel.h) -- eight blocks a
  *                            CU instead of four -- on batches of at least min_blocks blocks (default: twice what the
- *                            GPU's LDS-table waves take at once).  Output bytes never depend on it.
+ *                            GPU's LDS-table waves take at once, but no more than a host-buffer call's batch,
+ *                            SNAPPY_HIP_HOST_BATCH).  Output bytes never depend on it.
  *   SNAPPY_HIP_DEVICE        GPU of the pooled contexts (default 0)
  *   SNAPPY_HIP_HOST_BATCH    blocks per upload/compute/download batch (64 .. 65536, default 2048)
  *   SNAPPY_HIP_PIN_HOST      0 pageable copies (default) / 1, 2 page-lock the caller's buffers per call, per batch
