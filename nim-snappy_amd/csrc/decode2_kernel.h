@@ -197,14 +197,12 @@ extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn_window[];
 // step `s <- Z1024(s ^ dword)` per row): a row is final, and still in the ring, when its bytes are flushed, so
 // threads 256..511 take the rows the flush has just completed, their column registers live across the steps.
 // The framed stream (uncompressFramed, snappy.nim:231) then decodes on the ring kernel too.
-#ifndef D2_RING_MINWAVES  // (experiments: the register budget the compiler derives from "waves per SIMD")
-#define D2_RING_MINWAVES ((kD2Threads / 64 * d2_wgs_per_cu(WIN) + 3) / 4)
-#endif
-#ifndef D2_KATTR
-#define D2_KATTR
-#endif
+// (__launch_bounds__' second argument is waves per SIMD: 8 = four workgroups of eight waves a CU.  It also caps the scalar
+// registers -- 80 at eight waves a SIMD, the trap handler's 16 set aside: 45 are spilled to the lanes of a vector register;
+// at 7 the compiler takes 72 vector registers, and four workgroups no longer fit.  Round 6 measured that those spills are
+// ~3 % of what a block executes, profiles/r06_instruction_table.md.)
 template <uint32_t WIN, bool RCRC = false>
-__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? D2_RING_MINWAVES : 1) D2_KATTR void decode_indexed_kernel(Decode2Params prm) {
+__global__ __launch_bounds__(kD2Threads, WIN < kMaxBlockLen ? (kD2Threads / 64 * d2_wgs_per_cu(WIN) + 3) / 4 : 1) void decode_indexed_kernel(Decode2Params prm) {
   constexpr bool RING = WIN < kMaxBlockLen;
   static_assert(RING || !RCRC, "the whole-block instantiation checksums its window at the end");
   constexpr uint32_t kOutSink = WIN;
