@@ -143,3 +143,25 @@ def test_abi_caller_on_preallocated_buffers(orc):
     b = bench.AbiCaller(orc.lib, "sor_", src, cap_raw, cap_fr)
     a.check_against(b)
     assert a.raw[:a.raw_len].tobytes() == orc.encode(src) and a.fr[:a.fr_len].tobytes() == orc.encode_framed(src)
+
+
+def test_committed_bench_line_carries_every_quoted_number_inside_roofline():
+    """The driver's record keeps `roofline` and `cpu_baseline` whole and cuts the rest of the line to key names (round 5's
+    verdict), so every number README.md quotes lives inside `roofline`, each as value + fraction of the HBM peak.  The newest
+    committed line (profiles/*_bench_full.json, written by bench.py on the GPU box) must have them; the GPU suite asserts the
+    same keys on a fresh run (tests/test_gpu_batch.py::test_bench_contract_and_two_rank_path)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_full.json")))
+    assert files
+    line = [ln for ln in open(files[-1]) if ln.startswith("{")][0]
+    j = json.loads(line)
+    rf = j["roofline"]
+    for k in ("decompress_step", "compress", "round_trip", "framed", "framed_compress", "raw_buffer_1GiB", "raw_buffer_64MiB",
+              "class_R", "class_T_TEXT", "class_T_HTML"):
+        assert k in rf and rf[k]["value"] > 0 and 0 < rf[k]["frac"] < 1, k
+    assert abs(rf["decompress_step"]["value"] - j["value"]) < 0.01 * j["value"]
+    assert rf["framed"]["stream_bytes"] > 0 and rf["framed"]["calls"] >= 10 and 0 < rf["framed"]["over_value"] < 1
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(j["cpu_baseline"])
+    for cls, pc in j["per_class"].items():
+        assert pc["framed_decompress_GBps"] > 0, cls
