@@ -496,7 +496,9 @@ __global__ __launch_bounds__(TEAM ? 64 * kSplitWaves : 64) void index_units_kern
           const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)out_abs);
           prev = below ? v : e_abs;
         }
-        const uint32_t nin = lane == 0 ? e_abs : prev;
+        // (a position below my region -- the nearest region that is entered exits into one in between that still
+        // believes it is passed over -- says nothing about mine: I keep what I have, that region picks it up next round)
+        const uint32_t nin = lane == 0 ? e_abs : (prev < rs ? in_abs : prev);
         const bool changed = nin != in_abs;
         in_abs = nin;
         if (!ballot(changed)) break;
