@@ -115,15 +115,19 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
         s = gf2_mulmod(prm.col_mul[t], x);  // the 4*(256-t) bytes from here to the end
       }
     };
-    // (the rows' loads do not depend on the register: four go out together, the chain of table lookups
+    // (the rows' loads do not depend on the register: sixteen go out together (measured: 4 / 8 / 16 / 32 / 64 rows -- the framed 4 GiB stream 8.65 / 8.56 / 8.49 / 8.54 / 8.90 ms), the chain of table lookups
     // behind them -- a row at a time, each waiting for its own load, is bound by the trip to memory)
     uint32_t r = 0;
-    for (; r + 4 <= rows; r += 4) {
-      const uint32_t w0 = word(r), w1 = word(r + 1), w2 = word(r + 2), w3 = word(r + 3);
-      step(r, w0);
-      step(r + 1, w1);
-      step(r + 2, w2);
-      step(r + 3, w3);
+#ifndef CRC_ROWS_IN_FLIGHT
+#define CRC_ROWS_IN_FLIGHT 16
+#endif
+    constexpr uint32_t kIn = CRC_ROWS_IN_FLIGHT;
+    for (; r + kIn <= rows; r += kIn) {
+      uint32_t w[kIn];
+#pragma unroll
+      for (uint32_t k = 0; k < kIn; k++) w[k] = word(r + k);
+#pragma unroll
+      for (uint32_t k = 0; k < kIn; k++) step(r + k, w[k]);
     }
     for (; r < rows; r++) step(r, word(r));
     for (int d = 32; d >= 1; d >>= 1) s ^= __shfl_xor(s, d, 64);
@@ -210,8 +214,31 @@ struct ScanJobs {
   uint64_t* offsets[4];
   uint64_t n;
 };
+// gridDim.y > 1: the scan in tiles of one pass (kScanTile sizes) each, a workgroup a tile -- which first adds up every
+// size in front of its tile by itself (independent loads, no pass waits for another), then scans its tile from there:
+// 65 536 sizes in ~15 us instead of eight dependent passes of one workgroup (62 us).
+constexpr uint32_t kScanTile = kScanThreads * 8;  // (= one pass of scan_sizes_body)
 __global__ __launch_bounds__(kScanThreads) void scan_sizes_jobs_kernel(ScanJobs j) {
-  scan_sizes_body(j.sizes[blockIdx.x], j.n, 0, j.offsets[blockIdx.x]);
+  const uint32_t* const sizes = j.sizes[blockIdx.x];
+  uint64_t* const offsets = j.offsets[blockIdx.x];
+  if (gridDim.y == 1) {
+    scan_sizes_body(sizes, j.n, 0, offsets);
+    return;
+  }
+  const uint64_t t0 = (uint64_t)blockIdx.y * kScanTile;
+  if (blockIdx.y && t0 >= j.n) return;  // (tile 0 always runs: offsets[0] is written for n = 0 too)
+  __shared__ uint64_t s_part[kScanThreads / 64];
+  uint64_t part = 0;
+  for (uint64_t i = threadIdx.x; i < t0; i += kScanThreads) part += sizes[i];
+#pragma unroll
+  for (uint32_t d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+  __syncthreads();
+  uint64_t base = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kScanThreads / 64; k++) base += s_part[k];
+  const uint64_t left = j.n - (t0 < j.n ? t0 : j.n);
+  scan_sizes_body(sizes + t0, left < kScanTile ? left : kScanTile, base, offsets + t0);
 }
 
 // Copy slot i (src = slots + i*stride, sizes[i] bytes) to out + offsets[i].

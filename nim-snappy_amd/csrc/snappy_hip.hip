@@ -1004,7 +1004,10 @@ extern "C" int snappy_hip_uncompress_framed_d(snappy_hip_ctx* c, const uint8_t* 
         sj.sizes[1] = d_is_comp, sj.offsets[1] = d_comp_at;
         sj.sizes[2] = d_is_stored, sj.offsets[2] = d_stored_at;
         sj.n = (uint64_t)H;
-        LAUNCH(scan_sizes_jobs_kernel, dim3(3), dim3(kScanThreads), 0, s, sj);
+        // (tiles, a workgroup each, up to 2^20 chunks; beyond that a tile's own sum of what lies in front of it would be
+        // the longer part: one workgroup per scan, pass by pass)
+        const uint32_t tiles = H <= (1u << 20) ? (uint32_t)((H + kScanTile - 1) / kScanTile) : 1u;
+        LAUNCH(scan_sizes_jobs_kernel, dim3(3, tiles ? tiles : 1u), dim3(kScanThreads), 0, s, sj);
       }
       FrameScatterParams xp{};
       xp.in = d_in;
