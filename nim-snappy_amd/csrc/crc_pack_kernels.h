@@ -115,21 +115,32 @@ __global__ __launch_bounds__(kCrcThreads) void crc32c_units_kernel(CrcParams prm
         s = gf2_mulmod(prm.col_mul[t], x);  // the 4*(256-t) bytes from here to the end
       }
     };
-    // (the rows' loads do not depend on the register: sixteen go out together (measured: 4 / 8 / 16 / 32 / 64 rows -- the framed 4 GiB stream 8.65 / 8.56 / 8.49 / 8.54 / 8.90 ms), the chain of table lookups
-    // behind them -- a row at a time, each waiting for its own load, is bound by the trip to memory)
+    // (the rows' loads do not depend on the register: sixteen go out together -- measured with 4 / 8 / 16 / 32 / 64 rows:
+    // the framed 4 GiB stream 8.65 / 8.56 / 8.49 / 8.54 / 8.90 ms --, the chain of table lookups behind them; a row at a
+    // time, each waiting for its own load, is bound by the trip to memory)
+    // Only rows 0 and 1 can touch the message's start (pad < one row): they go through word(); every later row is a plain
+    // dword per thread, and nothing about its load is conditional -- a load under a condition is waited for where the
+    // branches join, one trip to HBM after the other.
     uint32_t r = 0;
+    for (; r < 2 && r < rows; r++) step(r, word(r));
 #ifndef CRC_ROWS_IN_FLIGHT
 #define CRC_ROWS_IN_FLIGHT 16
 #endif
     constexpr uint32_t kIn = CRC_ROWS_IN_FLIGHT;
-    for (; r + kIn <= rows; r += kIn) {
+    const uint8_t* const mine = msg + 4 * t - pad;  // my dword of row r at mine + r * row_bytes
+    for (; r < rows; r += kIn) {  // (a last, shorter batch loads its last row again instead of branching around loads)
       uint32_t w[kIn];
 #pragma unroll
-      for (uint32_t k = 0; k < kIn; k++) w[k] = word(r + k);
+      for (uint32_t k = 0; k < kIn; k++) w[k] = ld32u(mine + (uint64_t)(r + k < rows ? r + k : rows - 1) * row_bytes);
+      if (cp) {
 #pragma unroll
-      for (uint32_t k = 0; k < kIn; k++) step(r + k, w[k]);
+        for (uint32_t k = 0; k < kIn; k++)
+          if (r + k < rows) st32u(cp + 4 * t - pad + (uint64_t)(r + k) * row_bytes, w[k]);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kIn; k++)
+        if (r + k < rows) step(r + k, w[k]);
     }
-    for (; r < rows; r++) step(r, word(r));
     for (int d = 32; d >= 1; d >>= 1) s ^= __shfl_xor(s, d, 64);
     if ((t & 63) == 0) s_part[t >> 6] = s;
     __syncthreads();
